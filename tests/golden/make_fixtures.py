@@ -1,0 +1,378 @@
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE itself.
+
+Run only in the build container (needs /root/reference, which never travels):
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_fixtures.py [--only NAME]
+
+The reference's hot path is pure Python on top of torch; torch (CPU) is installed, so
+its own ``math_utils``, ``neural_nets.Vgg19``, ``LossBuilder``, ``prepare_img`` and
+``NeuralStyleTransfer.process`` are imported and executed unmodified.  Two packages it
+imports are absent offline and are supplied as in-process stand-in modules that carry
+NO hot-path arithmetic:
+
+* ``torchvision``: ``models.vgg19()`` returns the cfg-"E" ``features`` ``nn.Sequential``
+  (Conv2d 3x3 pad 1 / ReLU(inplace) / MaxPool2d 2x2) filled with the seeded synthetic
+  weights (no pretrained file exists offline); ``transforms.Compose/ToTensor/Lambda/
+  Normalize`` with torchvision's documented semantics for float32 HWC input.
+* ``cv2``: only so the module imports; no cv2 function is called by the paths used here.
+
+Fixtures hold data only (inputs, expected outputs); no reference source text.
+"""
+from __future__ import annotations
+
+import argparse
+import asyncio
+import contextlib
+import io
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("NST_REFERENCE_DIR", "/root/reference")
+sys.path.insert(0, ROOT)
+
+from oracle import cpu_ref  # noqa: E402  (synthetic input generators only)
+
+
+# ------------------------------------------------------------------ stand-ins
+def install_standins(weights):
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_CUBIC = 2
+    cv2.CV_64F = 6
+
+    def _absent(*a, **k):
+        raise RuntimeError("cv2 is absent offline; this path is not exercised by the fixtures")
+
+    for name in ("resize", "Sobel", "GaussianBlur", "getGaussianKernel", "imwrite", "cvtColor"):
+        setattr(cv2, name, _absent)
+    sys.modules["cv2"] = cv2
+
+    tv = types.ModuleType("torchvision")
+    models = types.ModuleType("torchvision.models")
+    transforms = types.ModuleType("torchvision.transforms")
+
+    cfg_e = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M",
+             512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+
+    def vgg19(pretrained=False, progress=True, **kw):
+        layers, cin, wi = [], 3, 0
+        for v in cfg_e:
+            if v == "M":
+                layers.append(torch.nn.MaxPool2d(kernel_size=2, stride=2))
+            else:
+                conv = torch.nn.Conv2d(cin, v, kernel_size=3, padding=1)
+                if wi < len(weights):
+                    with torch.no_grad():
+                        conv.weight.copy_(weights[wi][0])
+                        conv.bias.copy_(weights[wi][1])
+                wi += 1
+                layers += [conv, torch.nn.ReLU(inplace=True)]
+                cin = v
+        net = types.SimpleNamespace()
+        net.features = torch.nn.Sequential(*layers)
+        return net
+
+    models.vgg19 = vgg19
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToTensor:
+        def __call__(self, pic):
+            assert isinstance(pic, np.ndarray) and pic.dtype == np.float32 and pic.ndim == 3
+            return torch.from_numpy(np.ascontiguousarray(pic.transpose(2, 0, 1)))
+
+    class Lambda:
+        def __init__(self, fn):
+            self.fn = fn
+
+        def __call__(self, x):
+            return self.fn(x)
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean = torch.tensor(mean, dtype=torch.float32).view(-1, 1, 1)
+            self.std = torch.tensor(std, dtype=torch.float32).view(-1, 1, 1)
+
+        def __call__(self, x):
+            return (x - self.mean) / self.std
+
+    transforms.Compose, transforms.ToTensor = Compose, ToTensor
+    transforms.Lambda, transforms.Normalize = Lambda, Normalize
+    tv.models, tv.transforms = models, transforms
+    sys.modules["torchvision"] = tv
+    sys.modules["torchvision.models"] = models
+    sys.modules["torchvision.transforms"] = transforms
+
+
+def import_reference():
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    with contextlib.redirect_stdout(io.StringIO()):
+        import math_utils as ref_mu
+        import neural_nets as ref_nn
+        import neural_style_transfer as ref_nst
+    return ref_mu, ref_nn, ref_nst
+
+
+def sample_idx(n, k, seed):
+    return np.random.RandomState(seed).randint(0, n, size=k).astype(np.int64)
+
+
+def summarize(t: torch.Tensor, k=64, seed=7):
+    a = t.detach().reshape(-1).double()
+    idx = sample_idx(a.numel(), k, seed)
+    return {
+        "shape": np.array(t.shape, dtype=np.int64),
+        "sum": np.float64(a.sum()),
+        "abs_sum": np.float64(a.abs().sum()),
+        "sq_sum": np.float64((a * a).sum()),
+        "idx": idx,
+        "val": t.detach().reshape(-1)[torch.from_numpy(idx)].numpy().astype(np.float32),
+    }
+
+
+def save(name, **arrays):
+    flat = {}
+    for k, v in arrays.items():
+        if isinstance(v, dict):
+            for kk, vv in v.items():
+                flat[f"{k}.{kk}"] = vv
+        else:
+            flat[k] = v
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **flat)
+    print(f"wrote {path} ({os.path.getsize(path)} bytes)")
+
+
+# ------------------------------------------------------------------ fixtures
+def fx_kat(ref_mu, ref_nn, ref_nst, weights):
+    """Weight-free known answers straight from the reference's own functions."""
+    x = torch.arange(24, dtype=torch.float32).reshape(1, 2, 3, 4)
+    g = ref_mu.gram_matrix(x)
+    gu = ref_mu.gram_matrix(x, should_normalize=False)
+    y = (torch.arange(120).reshape(2, 3, 4, 5) ** 2 % 7).float()
+    tv = ref_mu.total_variation(y)
+    img = np.linspace(0, 1, 72, dtype=np.float32).reshape(4, 6, 3)
+    p = ref_nst.prepare_img(img, "cpu")
+    back = ref_nst.unprepare_img(p.clone())
+    r = torch.Generator().manual_seed(5)
+    xr = torch.randn(1, 5, 7, 9, generator=r)
+    save("kat",
+         gram_in=x.numpy(), gram=g.numpy(), gram_unnorm=gu.numpy(),
+         tv_in=y.numpy(), tv=np.float32(tv),
+         prep_in=img, prep=p.numpy(), unprep=back,
+         gram_rand_in=xr.numpy(), gram_rand=ref_mu.gram_matrix(xr).numpy(),
+         tv_rand=np.float32(ref_mu.total_variation(xr)))
+
+
+def fx_bicubic(ref_mu, ref_nn, ref_nst, weights):
+    """The reference's down-sample call (neural_style_transfer.py:173-176) fwd + autograd bwd,
+    on an even size (exact 1/2) and on an odd size (general scale)."""
+    out = {}
+    for tag, (h, w) in (("even", (16, 24)), ("odd", (15, 23)), ("tiny", (4, 6))):
+        g = torch.Generator().manual_seed(11)
+        x = torch.randn(1, 3, h, w, generator=g, requires_grad=True)
+        sw, sh = x.shape[2], x.shape[3]
+        y = torch.nn.functional.interpolate(x, size=(sw // 2, sh // 2), mode="bicubic")
+        gy = torch.randn(y.shape, generator=g)
+        (y * gy).sum().backward()
+        out[f"{tag}_x"] = x.detach().numpy()
+        out[f"{tag}_y"] = y.detach().numpy()
+        out[f"{tag}_gy"] = gy.numpy()
+        out[f"{tag}_gx"] = x.grad.numpy()
+    save("bicubic", **out)
+
+
+def fx_vgg(ref_mu, ref_nn, ref_nst, weights):
+    """Reference Vgg19 forward on a (1,3,48,80) input + d(sum of weighted outputs)/dx."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        net, cidx, sidx = ref_mu.prepare_model("vgg19", "cpu")
+    img = cpu_ref.synthetic_image(48, 80, seed=3)
+    x = ref_nst.prepare_img(img, "cpu").requires_grad_(True)
+    outs = net(x)
+    arrays = {"img": img, "content_index": np.int64(cidx), "style_indices": np.array(sidx, dtype=np.int64),
+              "layer_names": np.array(list(net.layer_names))}
+    loss = 0
+    g = torch.Generator().manual_seed(21)
+    for i, o in enumerate(outs):
+        arrays[f"out{i}"] = summarize(o, seed=100 + i)
+        wgt = torch.randn(o.shape, generator=g) / o.numel()
+        loss = loss + (o * wgt).sum()
+        arrays[f"gram{i}"] = summarize(ref_mu.gram_matrix(o), seed=200 + i)
+    loss.backward()
+    arrays["grad_seed"] = np.int64(21)
+    arrays["grad"] = x.grad.numpy()
+    # smallest full maps kept whole (cheap): relu5_1 and ReLU(conv4_2)
+    arrays["out5_full"] = outs[5].detach().numpy()
+    arrays["out4_full"] = outs[4].detach().numpy()
+    save("vgg_48x80", **arrays)
+
+
+def _levels(h, w, nlev, seed):
+    """Pyramid of synthetic images, highest-res first, each level generated from the
+    level-0 'original' by bicubic resize (same rule cv2 INTER_CUBIC documents)."""
+    top = cpu_ref.synthetic_image(h, w, seed)
+    out = [top]
+    t = torch.from_numpy(top).permute(2, 0, 1).unsqueeze(0)
+    for l in range(1, nlev):
+        d = torch.nn.functional.interpolate(t, size=(h >> l, w >> l), mode="bicubic", align_corners=False)
+        out.append(d.squeeze(0).permute(1, 2, 0).contiguous().numpy())
+    return out
+
+
+def _ref_closure(ref_mu, ref_nst, content_levels, style_levels, x_img, cw, sw, tvw):
+    """Teacher-forced closure through the reference's LossBuilder (one call, no optimiser)."""
+    with contextlib.redirect_stdout(io.StringIO()):
+        net, cidx, sidx = ref_mu.prepare_model("vgg19", "cpu")
+    builders = [ref_nst.LossBuilder(cidx, sidx, ref_nst.prepare_img(c, "cpu"), ref_nst.prepare_img(s, "cpu"),
+                                    net, cw, sw, tvw) for c, s in zip(content_levels, style_levels)]
+    x = ref_nst.prepare_img(x_img, "cpu").requires_grad_(True)
+    levels, total, rows = [x], None, []
+    for i, b in enumerate(builders):
+        if i > 0:
+            p = levels[i - 1]
+            levels.append(torch.nn.functional.interpolate(p, size=(p.shape[2] // 2, p.shape[3] // 2), mode="bicubic"))
+        t, c, s, tv = b.build(levels[i])
+        total = t if total is None else 1.0 * total + t
+        rows.append([float(t), float(c), float(s), float(tv)])
+    total.backward()
+    return float(total), np.array(rows, dtype=np.float64), x.grad.detach()
+
+
+def fx_closure_small(ref_mu, ref_nn, ref_nst, weights):
+    """2 levels, 64x96 + 32x48: inputs, losses and the whole gradient."""
+    cl = _levels(64, 96, 2, seed=1)
+    sl = _levels(64, 96, 2, seed=2)
+    x_img = (0.6 * cl[0] + 0.4 * cpu_ref.synthetic_image(64, 96, seed=9)).astype(np.float32)
+    total, rows, grad = _ref_closure(ref_mu, ref_nst, cl, sl, x_img, 1e3, 4e5, 1e2)
+    save("closure_64x96_L1", content0=cl[0], content1=cl[1], style0=sl[0], style1=sl[1], x_img=x_img,
+         total=np.float64(total), rows=rows, grad=grad.numpy())
+
+
+def fx_closure_odd(ref_mu, ref_nn, ref_nst, weights):
+    """1 level with awkward (non multiple of 16) size 50x76 and a different-size style image."""
+    c = [cpu_ref.synthetic_image(50, 76, seed=1)]
+    s = [cpu_ref.synthetic_image(44, 58, seed=2)]
+    x_img = (0.5 * c[0] + 0.5 * cpu_ref.synthetic_image(50, 76, seed=9)).astype(np.float32)
+    total, rows, grad = _ref_closure(ref_mu, ref_nst, c, s, x_img, 1e3, 4e5, 1e2)
+    save("closure_50x76_L0", content0=c[0], style0=s[0], x_img=x_img,
+         total=np.float64(total), rows=rows, grad=grad.numpy())
+
+
+def fx_closure_L0(ref_mu, ref_nn, ref_nst, weights):
+    """256x384 single level (BASELINE config 1 geometry): losses + gradient summary; inputs from seeds."""
+    cl = _levels(256, 384, 1, seed=1)
+    sl = _levels(256, 384, 1, seed=2)
+    x_img = cl[0]
+    total, rows, grad = _ref_closure(ref_mu, ref_nst, cl, sl, x_img, 1e3, 4e5, 1e2)
+    save("closure_256x384_L0", total=np.float64(total), rows=rows, grad=summarize(grad, k=256, seed=31),
+         content_sum=np.float64(cl[0].astype(np.float64).sum()), style_sum=np.float64(sl[0].astype(np.float64).sum()))
+
+
+def _run_reference_process(ref_mu, ref_nst, content_levels, style_levels, init_img, optimizer, iters,
+                           lbfgs_max_eval=None):
+    """Runs the reference's NeuralStyleTransfer.process unmodified; records per-closure rows by
+    wrapping LossBuilder.build, and the image after every optimiser step."""
+    rec, imgs = [], []
+    orig_build = ref_nst.LossBuilder.build
+
+    def build(self, x):
+        out = orig_build(self, x)
+        rec.append([float(v) for v in out])
+        return out
+
+    ref_nst.LossBuilder.build = build
+    orig_lbfgs = ref_nst.LBFGS
+    if lbfgs_max_eval is not None:
+        # legacy line-search behaviour through the constructor argument only
+        ref_nst.LBFGS = lambda params, **kw: orig_lbfgs(params, max_eval=lbfgs_max_eval, **kw)
+    try:
+        nst = ref_nst.NeuralStyleTransfer(torch.device("cpu"), "vgg19", style_levels, optimizer)
+
+        async def go():
+            async for img, step in nst.process(content_levels, init_img, 10.0, iters, 1e3, 4e5, 1e2, "fx"):
+                imgs.append((img.copy(), step))
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            asyncio.run(go())
+    finally:
+        ref_nst.LossBuilder.build = orig_build
+        ref_nst.LBFGS = orig_lbfgs
+        torch.autograd.set_detect_anomaly(False)
+    nlev = len(content_levels)
+    rows = np.array(rec, dtype=np.float64).reshape(-1, nlev, 4)
+    return rows, imgs
+
+
+def fx_adam_L0(ref_mu, ref_nn, ref_nst, weights):
+    """BASELINE config 1: single 384x256 level, 50 Adam iterations, content image as init."""
+    cl = _levels(256, 384, 1, seed=1)
+    sl = _levels(256, 384, 1, seed=2)
+    rows, imgs = _run_reference_process(ref_mu, ref_nst, cl, sl, cl[0], "adam", 50)
+    final = torch.from_numpy(imgs[-1][0])
+    save("traj_adam_256x384_50", rows=rows, steps=np.array([s for _, s in imgs], dtype=np.int64),
+         final=summarize(final, k=256, seed=41),
+         img_after_1=summarize(torch.from_numpy(imgs[0][0]), k=64, seed=42))
+
+
+def fx_adam_small(ref_mu, ref_nn, ref_nst, weights):
+    """2-level 64x96 Adam, 12 iterations, whole final image stored."""
+    cl = _levels(64, 96, 2, seed=1)
+    sl = _levels(64, 96, 2, seed=2)
+    rows, imgs = _run_reference_process(ref_mu, ref_nst, cl, sl, cl[0], "adam", 12)
+    save("traj_adam_64x96_L1_12", rows=rows, steps=np.array([s for _, s in imgs], dtype=np.int64),
+         final=imgs[-1][0], after_1=imgs[0][0])
+
+
+def fx_lbfgs_small(ref_mu, ref_nn, ref_nst, weights):
+    """2-level 128x192 L-BFGS, 40 closures, as shipped (torch 2.10: max_ls = 0) and with
+    max_eval=26 (legacy line search)."""
+    cl = _levels(128, 192, 2, seed=1)
+    sl = _levels(128, 192, 2, seed=2)
+    for tag, me, iters in (("shipped", None, 40), ("legacy", 26, 40)):
+        rows, imgs = _run_reference_process(ref_mu, ref_nst, cl, sl, cl[0], "lbfgs", iters, lbfgs_max_eval=me)
+        accepted = [True]
+        for (a, _), (b, _) in zip(imgs[:-1], imgs[1:]):
+            accepted.append(bool(np.any(a != b)))
+        accepted[0] = bool(np.any(imgs[0][0] != cl[0]))
+        save(f"traj_lbfgs_128x192_L1_{tag}", rows=rows,
+             steps=np.array([s for _, s in imgs], dtype=np.int64),
+             moved=np.array(accepted, dtype=np.bool_),
+             final=summarize(torch.from_numpy(imgs[-1][0]), k=256, seed=51))
+
+
+ALL = {f.__name__[3:]: f for f in (fx_kat, fx_bicubic, fx_vgg, fx_closure_small, fx_closure_odd, fx_closure_L0,
+                                   fx_adam_small, fx_lbfgs_small, fx_adam_L0)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    args = ap.parse_args()
+    torch.manual_seed(0)
+    weights = cpu_ref.synthetic_vgg19_weights()
+    install_standins(weights)
+    ref_mu, ref_nn, ref_nst = import_reference()
+    for name, fn in ALL.items():
+        if args.only and name not in args.only:
+            continue
+        print(f"== {name}")
+        fn(ref_mu, ref_nn, ref_nst, weights)
+
+
+if __name__ == "__main__":
+    main()
