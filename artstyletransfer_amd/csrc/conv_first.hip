@@ -1,0 +1,146 @@
+// conv_first.hip - conv1_1 of VGG19 (3 -> 64 channels, torchvision features[0:2]) read straight
+// from the planar (3,H,W) image, and its input gradient (64 -> 3) written straight into the
+// planar pixel gradient.  Both are HBM-bound (13 flop/B): the 64-channel side is streamed once.
+//
+// Forward: implicit GEMM with K = 27 (padded to 28) on v_mfma_f32_32x32x2_f32; the 28x64 weight
+// table lives in registers, the 3-plane halo patch in LDS.
+#include <hip/hip_runtime.h>
+
+#include "nst_kernels.h"
+
+namespace nst {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+constexpr int F_TH = 16, F_TW = 16;           // block tile: 16 x 16 pixels, 4 waves of 4 rows
+constexpr int F_PH = F_TH + 2, F_PW = F_TW + 2;
+constexpr int F_PLANE = F_PH * F_PW;
+
+// LDS offset (floats) of tap k = c*9 + ky*3 + kx relative to the pixel's own patch position
+__host__ __device__ constexpr int tap_off(int k) {
+    return (k >= 27) ? 0 : (k / 9) * F_PLANE + ((k % 9) / 3) * F_PW + (k % 3);
+}
+}  // namespace
+
+__global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restrict__ x, int H, int W,
+                                                          const float* __restrict__ wk,
+                                                          const float* __restrict__ bias, float* __restrict__ out) {
+    __shared__ float patch[3 * F_PLANE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int tiles_x = (W + F_TW - 1) / F_TW;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int y0 = ty * F_TH, x0 = tx * F_TW;
+
+    for (int u = tid; u < 3 * F_PLANE; u += 256) {
+        const int c = u / F_PLANE;
+        const int r = (u % F_PLANE) / F_PW;
+        const int col = u % F_PW;
+        const int gy = y0 - 1 + r, gx = x0 - 1 + col;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[((size_t)c * H + gy) * W + gx];
+        patch[u] = v;
+    }
+
+    // B operand: lane (n = l31, k-half) holds W[k = 2*kk + half][nt*32 + n]
+    float bw[14][2];
+#pragma unroll
+    for (int kk = 0; kk < 14; ++kk) {
+        const int k = 2 * kk + half;
+        bw[kk][0] = wk[k * 64 + l31];
+        bw[kk][1] = wk[k * 64 + 32 + l31];
+    }
+    __syncthreads();
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int prow = wave * 4 + (l31 >> 4);
+    const int pcol = l31 & 15;
+    const int base0 = prow * F_PW + pcol;           // M-tile 0: rows wave*4 + {0,1}
+    const int base1 = (prow + 2) * F_PW + pcol;     // M-tile 1: rows wave*4 + {2,3}
+#pragma unroll
+    for (int kk = 0; kk < 14; ++kk) {
+        const int off = half ? tap_off(2 * kk + 1) : tap_off(2 * kk);
+        const float a0 = patch[base0 + off];
+        const float a1 = patch[base1 + off];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bw[kk][0], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bw[kk][1], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw[kk][0], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw[kk][1], acc[1][1], 0, 0, 0);
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int co = nt * 32 + l31;
+        const float bv = bias[co];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int y = y0 + wave * 4 + mt * 2 + (m >> 4);
+                const int xx = x0 + (m & 15);
+                if (y < H && xx < W) out[((size_t)y * W + xx) * 64 + co] = fmaxf(acc[mt][nt][r] + bv, 0.f);
+            }
+    }
+}
+
+hipError_t launch_conv1_1_fwd(const float* x, int H, int W, const float* wk, const float* bias, float* out,
+                              hipStream_t stream) {
+    const int blocks = ((H + F_TH - 1) / F_TH) * ((W + F_TW - 1) / F_TW);
+    hipLaunchKernelGGL(conv1_1_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, H, W, wk, bias, out);
+    return hipGetLastError();
+}
+
+// Input gradient of conv1_1: gx[c][y][x] = sum_{tap, co} g[y+dy-1][x+dx-1][co] * wd[tap][co][c]
+// (wd holds the tap-flipped weights).  One pixel per lane, three accumulators; the weights are
+// wave-uniform and come through the scalar path.
+__global__ __launch_bounds__(256) void conv1_1_dgrad_kernel(const float* __restrict__ g, int H, int W,
+                                                            const float* __restrict__ wd, float* __restrict__ gx) {
+    const size_t HW = (size_t)H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (size_t)gridDim.x * blockDim.x) {
+        const int xx = (int)(i % W);
+        const int y = (int)(i / W);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int sy = y + t / 3 - 1, sx = xx + t % 3 - 1;
+            if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
+            const f32x4* src = reinterpret_cast<const f32x4*>(g + ((size_t)sy * W + sx) * 64);
+            const f32x4* wv = reinterpret_cast<const f32x4*>(wd + t * 64 * 4);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const f32x4 v = src[q];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 w = wv[q * 4 + k];
+                    a0 += v[k] * w[0];
+                    a1 += v[k] * w[1];
+                    a2 += v[k] * w[2];
+                }
+            }
+        }
+        gx[i] = a0;
+        gx[HW + i] = a1;
+        gx[2 * HW + i] = a2;
+    }
+}
+
+hipError_t launch_conv1_1_dgrad(const float* g, int H, int W, const float* wd, float* gx, hipStream_t stream) {
+    const size_t HW = (size_t)H * W;
+    size_t blocks = (HW + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(conv1_1_dgrad_kernel, dim3((int)blocks), dim3(256), 0, stream, g, H, W, wd, gx);
+    return hipGetLastError();
+}
+
+}  // namespace nst

@@ -1,0 +1,261 @@
+// gram.hip - Gram matrix G = F F^T / (C h w) of an NHWC feature map (math_utils.py:26-34) on the
+// gfx950 fp32 matrix cores, split over the pixel dimension with an ordered two-stage reduction
+// (bitwise reproducible; no float atomics).
+//
+// With pixel-major activations A[n][c] the Gram is A^T A: both MFMA operands are rows of the same
+// LDS tile and lane l of v_mfma_f32_32x32x2_f32 wants A[k = l>>5][c = l&31], i.e. 32 consecutive
+// floats per half-wave: conflict-free ds_read_b32, no transpose anywhere.  Only tiles on or above
+// the diagonal are computed; the finish kernel mirrors them.
+#include <hip/hip_runtime.h>
+
+#include "nst_kernels.h"
+
+namespace nst {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int TS>
+struct GramCfg {
+    static constexpr int KP = (TS == 128) ? 32 : 128;     // pixels per staged chunk
+    static constexpr int SIDES = (TS == 128) ? 2 : 1;
+    static constexpr int UNITS = KP * TS / 4;              // 16-byte units per side per chunk
+    static constexpr int PER_T = UNITS / 256;
+    static constexpr int SIDE_FLOATS = KP * TS;
+    static constexpr int BUF_FLOATS = SIDES * SIDE_FLOATS;
+    static constexpr int LDS_BYTES = 2 * BUF_FLOATS * 4;   // 64 KiB in both shapes
+};
+
+template <int TS>
+__global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ f, size_t N, int C, int nsplit,
+                                                           size_t pix_per_split, float* __restrict__ part) {
+    using G = GramCfg<TS>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int split = blockIdx.x % nsplit;
+    int tp = blockIdx.x / nsplit;
+    const int T = C / TS;
+    int ti = 0;
+    while (tp >= T - ti) { tp -= T - ti; ++ti; }
+    const int tj = ti + tp;
+    const bool diag = (ti == tj);
+
+    const size_t p0 = (size_t)split * pix_per_split;
+    size_t p1 = p0 + pix_per_split;
+    if (p1 > N) p1 = N;
+    const int nchunks = (p0 < p1) ? (int)((p1 - p0 + G::KP - 1) / G::KP) : 0;
+
+    const int wm = (TS == 128) ? (wave & 1) : 0;
+    const int wn = (TS == 128) ? (wave >> 1) : 0;
+    const int kbase = (TS == 128) ? 0 : 32 * wave;
+
+    f32x4 ra[G::PER_T];
+    f32x4 rb[G::PER_T];
+
+    auto load = [&](int chunk) {
+        const size_t pc = p0 + (size_t)chunk * G::KP;
+#pragma unroll
+        for (int i = 0; i < G::PER_T; ++i) {
+            const int u = tid + i * 256;
+            const int pix = u / (TS / 4);
+            const int q = u - pix * (TS / 4);
+            const size_t gp = pc + pix;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (gp < p1) {
+                va = *reinterpret_cast<const f32x4*>(f + gp * C + ti * TS + q * 4);
+                if (G::SIDES == 2 && !diag) vb = *reinterpret_cast<const f32x4*>(f + gp * C + tj * TS + q * 4);
+            }
+            ra[i] = va;
+            rb[i] = vb;
+        }
+    };
+    auto store = [&](int buf) {
+        float* base = smem + buf * G::BUF_FLOATS;
+#pragma unroll
+        for (int i = 0; i < G::PER_T; ++i) {
+            const int u = tid + i * 256;
+            *reinterpret_cast<f32x4*>(base + u * 4) = ra[i];
+            if (G::SIDES == 2 && !diag) *reinterpret_cast<f32x4*>(base + G::SIDE_FLOATS + u * 4) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (nchunks > 0) load(0);
+    int cur = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        store(cur);
+        __syncthreads();
+        if (c + 1 < nchunks) load(c + 1);
+        const float* abase = smem + cur * G::BUF_FLOATS;
+        const float* bbase = (G::SIDES == 2 && !diag) ? abase + G::SIDE_FLOATS : abase;
+        const float* arow = abase + (kbase + half) * TS + wm * 64 + l31;
+        const float* brow = bbase + (kbase + half) * TS + wn * 64 + l31;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) {
+            const float a0 = arow[k2 * 2 * TS];
+            const float a1 = arow[k2 * 2 * TS + 32];
+            const float b0 = brow[k2 * 2 * TS];
+            const float b1 = brow[k2 * 2 * TS + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        cur ^= 1;
+    }
+
+    float* slab = part + (size_t)split * C * C;
+    if (TS == 128) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int row = ti * TS + wm * 64 + mt * 32 + m;
+                    const int col = tj * TS + wn * 64 + nt * 32 + l31;
+                    slab[(size_t)row * C + col] = acc[mt][nt][r];
+                }
+    } else {
+        // the four waves hold partial sums over disjoint pixel rows: combine through LDS in wave order
+        __syncthreads();
+        float* mine = smem + wave * 4096;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    mine[(mt * 32 + m) * 64 + nt * 32 + l31] = acc[mt][nt][r];
+                }
+        __syncthreads();
+        for (int e = tid; e < 4096; e += 256) {
+            const float s = ((smem[e] + smem[4096 + e]) + smem[8192 + e]) + smem[12288 + e];
+            const int row = ti * TS + (e >> 6), col = tj * TS + (e & 63);
+            slab[(size_t)row * C + col] = s;
+        }
+    }
+}
+
+// generic fallback for channel counts that are not a multiple of 64 (unit-parity API only)
+__global__ void gram_generic_kernel(const float* __restrict__ f, size_t N, int C, float* __restrict__ part) {
+    const int i = blockIdx.x / C, j = blockIdx.x % C;
+    __shared__ float sh[256];
+    float s = 0.f;
+    for (size_t n = threadIdx.x; n < N; n += blockDim.x) s += f[n * C + i] * f[n * C + j];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[(size_t)i * C + j] = sh[0];
+}
+
+// 64-wide tiles have one operand side only, so that shape serves C == 64 alone
+static inline int gram_ts(int C) { return (C % 128 == 0) ? 128 : ((C == 64) ? 64 : 0); }
+
+int gram_nsplit(int C, size_t N) {
+    const int ts = gram_ts(C);
+    if (ts == 0) return 1;
+    const int kp = (ts == 128) ? 32 : 128;
+    const int T = C / ts;
+    const int pairs = T * (T + 1) / 2;
+    const size_t chunks = (N + kp - 1) / kp;
+    size_t ns = 512 / pairs;
+    const size_t by_bytes = ((size_t)32 << 20) / ((size_t)C * C * 4);
+    if (ns > by_bytes) ns = by_bytes;
+    if (ns > chunks) ns = chunks;
+    if (ns < 1) ns = 1;
+    const size_t cps = (chunks + ns - 1) / ns;
+    return (int)((chunks + cps - 1) / cps);
+}
+
+int gram_nslabs(int C, int nsplit) { (void)C; return nsplit; }
+
+hipError_t gram_init_device() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_partial_kernel<128>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, GramCfg<128>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_partial_kernel<64>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GramCfg<64>::LDS_BYTES);
+}
+
+hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, float* part, hipStream_t stream) {
+    const int ts = gram_ts(C);
+    if (ts == 0) {
+        hipLaunchKernelGGL(gram_generic_kernel, dim3(C * C), dim3(256), 0, stream, f, N, C, part);
+        return hipGetLastError();
+    }
+    const int kp = (ts == 128) ? 32 : 128;
+    const int T = C / ts;
+    const int pairs = T * (T + 1) / 2;
+    const size_t chunks = (N + kp - 1) / kp;
+    const size_t cps = (chunks + nsplit - 1) / nsplit;
+    const size_t pix_per_split = cps * kp;
+    if (ts == 128) {
+        hipLaunchKernelGGL(gram_partial_kernel<128>, dim3(pairs * nsplit), dim3(256), GramCfg<128>::LDS_BYTES, stream, f,
+                           N, C, nsplit, pix_per_split, part);
+    } else {
+        hipLaunchKernelGGL(gram_partial_kernel<64>, dim3(pairs * nsplit), dim3(256), GramCfg<64>::LDS_BYTES, stream, f,
+                           N, C, nsplit, pix_per_split, part);
+    }
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ double block_sum_256(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ part, int nslabs, int C, int ts,
+                                                          float divisor, const float* __restrict__ target, float coef,
+                                                          float* __restrict__ gram_out, float* __restrict__ S,
+                                                          double* __restrict__ mse_partial) {
+    __shared__ double sh[4];
+    const size_t CC = (size_t)C * C;
+    double sq = 0.0;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < CC; e += (size_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / C), j = (int)(e % C);
+        // tiles below the diagonal were not computed: read the mirrored element
+        size_t src = e;
+        if (ts > 0 && (i / ts) > (j / ts)) src = (size_t)j * C + i;
+        float s = 0.f;
+        for (int k = 0; k < nslabs; ++k) s += part[(size_t)k * CC + src];
+        const float g = s / divisor;      // torch: gram /= ch*h*w
+        if (gram_out) gram_out[e] = g;
+        if (target) {
+            const float d = g - target[e];
+            sq += (double)d * (double)d;
+            if (S) S[e] = coef * d;
+        }
+    }
+    const double b = block_sum_256(sq, sh);
+    if (mse_partial && threadIdx.x == 0) mse_partial[blockIdx.x] = b;
+}
+
+hipError_t launch_gram_finish(const float* part, int nslabs, int C, float divisor, const float* target, float coef,
+                              float* gram_out, float* S, double* mse_partial, hipStream_t stream) {
+    hipLaunchKernelGGL(gram_finish_kernel, dim3(GRAM_FIN_BLOCKS), dim3(256), 0, stream, part, nslabs, C, gram_ts(C),
+                       divisor, target, coef, gram_out, S, mse_partial);
+    return hipGetLastError();
+}
+
+}  // namespace nst

@@ -1,0 +1,732 @@
+// nst_api.cpp - C ABI of libnst_hip.so (include/nst_hip.h): context (VGG19 weights re-laid-out for
+// the gfx950 kernels), per-job pyramid workspace, the closure (forward + losses + backward of
+// every pyramid level, one HIP stream per level), and the Adam / L-BFGS drivers.
+//
+// Host-side control only; every FLOP and byte of the path is in the .hip kernels.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nst_hip.h"
+#include "nst_kernels.h"
+
+using namespace nst;
+
+namespace {
+
+constexpr int NL = NST_VGG19_CONVS;
+const int kCin[NL] = {3, 64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512};
+const int kCout[NL] = {64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512};
+const int kScale[NL] = {0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4};      // log2 of the spatial divisor
+const int kPoolAfter[4] = {1, 3, 7, 11};
+const int kStyleLayer[5] = {0, 2, 4, 8, 12};                          // relu1_1, relu2_1, relu3_1, relu4_1, relu5_1
+constexpr int kContentLayer = 9;                                       // ReLU(conv4_2)
+// reference output index (neural_nets.py:22) -> conv layer
+const int kTapLayer[6] = {0, 2, 4, 8, 9, 12};
+
+thread_local std::string g_err;
+
+struct ActSet {                 // activations of one forward pass, NHWC
+    int h[NL], w[NL];
+    float* act[NL] = {};
+    float* pool[4] = {};
+    size_t bytes = 0;
+};
+
+enum KClass { K_CONV3 = 0, K_GRAM = 1, K_CONV1 = 2, K_OTHER = 3, K_NCLASS = 4 };
+
+struct TimedLaunch { hipEvent_t a, b; int cls; double flops; };
+
+struct LevelWs {
+    int h = 0, w = 0;
+    ActSet acts;
+    float* gbuf[2] = {};
+    size_t gbuf_floats = 0;
+    float* xl = nullptr;        // level image (levels >= 1), planar
+    float* gxl = nullptr;       // its gradient (levels >= 1), planar
+    float* content_t = nullptr; // NHWC target ReLU(conv4_2)
+    size_t content_n = 0;
+    float* gram_t[5] = {};
+    float* S[5] = {};
+    float* gram_part = nullptr;
+    size_t gram_part_floats = 0;
+    double* style_partial[5] = {};
+    double* content_partial = nullptr;
+    double* tv_partial = nullptr;
+    float* tv_means = nullptr;
+    bool targets = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;
+};
+
+}  // namespace
+
+struct nst_ctx {
+    int device = 0;
+    std::string err;
+    float* wf[NL] = {};
+    float* wd[NL] = {};
+    float* bias[NL] = {};
+    float* w11k = nullptr;      // [28][64]
+    float* w11d = nullptr;      // [9][64][4]
+    int levels = 0;
+    LevelWs lv[NST_MAX_LEVELS];
+    hipEvent_t fork = nullptr;
+    size_t bytes = 0;
+    bool single_stream = false;
+    // timing
+    int timing = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    std::vector<TimedLaunch> timed;
+    bool timed_valid = false;
+};
+
+namespace {
+
+int fail(nst_ctx* ctx, int code, const std::string& msg) {
+    if (ctx) ctx->err = msg; else g_err = msg;
+    return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                         \
+    do {                                                                                          \
+        hipError_t _e = (expr);                                                                   \
+        if (_e != hipSuccess)                                                                     \
+            return fail(ctx, NST_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+    } while (0)
+
+#define NSTCHK(expr)                 \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != NST_OK) return _r; \
+    } while (0)
+
+int dev_alloc(nst_ctx* ctx, void** p, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail(ctx, NST_E_NOMEM, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    ctx->bytes += bytes;
+    return NST_OK;
+}
+template <typename T>
+int dev_alloc_t(nst_ctx* ctx, T** p, size_t count) { return dev_alloc(ctx, reinterpret_cast<void**>(p), count * sizeof(T)); }
+
+void dev_free(void* p) { if (p) (void)hipFree(p); }
+
+int alloc_acts(nst_ctx* ctx, ActSet& a, int h, int w) {
+    a.bytes = 0;
+    for (int l = 0; l < NL; ++l) {
+        a.h[l] = h >> kScale[l];
+        a.w[l] = w >> kScale[l];
+        if (a.h[l] < 1 || a.w[l] < 1) return fail(ctx, NST_E_ARG, "image too small for VGG19 (needs >= 16 px per side)");
+        const size_t n = (size_t)a.h[l] * a.w[l] * kCout[l];
+        NSTCHK(dev_alloc_t(ctx, &a.act[l], n));
+        a.bytes += n * 4;
+    }
+    for (int k = 0; k < 4; ++k) {
+        const int l = kPoolAfter[k];
+        const size_t n = (size_t)(a.h[l] / 2) * (a.w[l] / 2) * kCout[l];
+        NSTCHK(dev_alloc_t(ctx, &a.pool[k], n));
+        a.bytes += n * 4;
+    }
+    return NST_OK;
+}
+void free_acts(nst_ctx* ctx, ActSet& a) {
+    for (int l = 0; l < NL; ++l) { dev_free(a.act[l]); a.act[l] = nullptr; }
+    for (int k = 0; k < 4; ++k) { dev_free(a.pool[k]); a.pool[k] = nullptr; }
+    if (ctx->bytes >= a.bytes) ctx->bytes -= a.bytes;
+    a.bytes = 0;
+}
+
+int pool_index_after(int l) {
+    for (int k = 0; k < 4; ++k) if (kPoolAfter[k] == l) return k;
+    return -1;
+}
+
+// ---- timed launches ---------------------------------------------------------------------------
+struct Timer {
+    nst_ctx* ctx; hipStream_t s; bool on; size_t slot;
+    Timer(nst_ctx* c, hipStream_t st, int cls, double flops) : ctx(c), s(st), on(false), slot(0) {
+        if (c->timing >= 2 && c->ev_used + 2 <= c->ev_pool.size()) {
+            on = true;
+            TimedLaunch t{c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1], cls, flops};
+            c->ev_used += 2;
+            slot = c->timed.size();
+            c->timed.push_back(t);
+            (void)hipEventRecord(t.a, st);
+        }
+    }
+    ~Timer() { if (on) (void)hipEventRecord(ctx->timed[slot].b, s); }
+};
+
+double conv_flops(int h, int w, int cin, int cout, int taps) { return 2.0 * h * w * (double)cin * cout * taps; }
+
+// ---- network forward ----------------------------------------------------------------------------
+int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s, int last_layer = NL - 1) {
+    {
+        Timer t(ctx, s, K_CONV1, conv_flops(h, w, 3, 64, 9));
+        HIPCHK(ctx, launch_conv1_1_fwd(x, h, w, ctx->w11k, ctx->bias[0], a.act[0], s));
+    }
+    for (int l = 1; l <= last_layer; ++l) {
+        const int pk = pool_index_after(l - 1);
+        const float* in = (pk >= 0) ? a.pool[pk] : a.act[l - 1];
+        ConvParams p{};
+        p.in = in; p.wt = ctx->wf[l]; p.bias = ctx->bias[l]; p.addend = nullptr; p.mask = nullptr; p.out = a.act[l];
+        p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCin[l]; p.Cout = kCout[l]; p.relu = 1;
+        {
+            Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9));
+            HIPCHK(ctx, launch_conv_mfma(p, 9, s));
+        }
+        const int pa = pool_index_after(l);
+        if (pa >= 0 && l < last_layer) {
+            Timer t(ctx, s, K_OTHER, 0);
+            HIPCHK(ctx, launch_maxpool_fwd(a.act[l], a.h[l], a.w[l], kCout[l], a.pool[pa], s));
+        }
+    }
+    return NST_OK;
+}
+
+// gradient injected at a tap layer, w.r.t. its post-ReLU activation
+struct Inject {
+    const float* S = nullptr;        // Gram backward: dF = F * S (1x1 conv of the activation itself)
+    const float* direct = nullptr;   // or a ready NHWC gradient
+    bool content = false;            // or the content MSE gradient (closure only)
+};
+
+struct ContentJob { const float* target; size_t n; float coef; double* partial; };
+
+// Backward through the network down to the planar image gradient gx (overwritten).
+// inj[l] describes what enters at conv layer l; gbuf: two NHWC scratch buffers of the largest size.
+int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, float* gbuf0, float* gbuf1, float* gx,
+             int h, int w, hipStream_t s) {
+    float* cur = gbuf0;     // holds the gradient w.r.t. the pre-ReLU output of the layer being processed
+    float* oth = gbuf1;
+    // top: layer 12
+    {
+        const int l = NL - 1;
+        const size_t n = (size_t)a.h[l] * a.w[l] * kCout[l];
+        if (inj[l].S) {
+            ConvParams p{};
+            p.in = a.act[l]; p.wt = inj[l].S; p.out = cur; p.mask = a.act[l];
+            p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCout[l]; p.Cout = kCout[l];
+            Timer t(ctx, s, K_GRAM, conv_flops(p.H, p.W, p.Cin, p.Cout, 1));
+            HIPCHK(ctx, launch_conv_mfma(p, 1, s));
+        } else if (inj[l].direct) {
+            Timer t(ctx, s, K_OTHER, 0);
+            HIPCHK(ctx, launch_relu_mask(a.act[l], inj[l].direct, n, cur, s));
+        } else {
+            HIPCHK(ctx, hipMemsetAsync(cur, 0, n * 4, s));
+        }
+    }
+    for (int l = NL - 1; l >= 1; --l) {
+        // cur = g(pre-ReLU of layer l), dims of layer l, kCout[l] channels.  dgrad -> gradient w.r.t.
+        // layer l's input: either pool[k] (then un-pool into act[l-1]'s shape) or act[l-1] directly.
+        const int pk = pool_index_after(l - 1);
+        ConvParams p{};
+        p.in = cur; p.wt = ctx->wd[l]; p.out = oth;
+        p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCout[l]; p.Cout = kCin[l];
+        if (pk >= 0) {
+            {
+                Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9));
+                HIPCHK(ctx, launch_conv_mfma(p, 9, s));
+            }
+            // oth = g(pool[pk]); un-pool through act[l-1] with its ReLU mask -> cur
+            Timer t(ctx, s, K_OTHER, 0);
+            HIPCHK(ctx, launch_maxpool_bwd_relu(a.act[l - 1], oth, a.h[l - 1], a.w[l - 1], kCout[l - 1], cur, s));
+            // cur now holds g(pre-ReLU of layer l-1); no tap layer sits directly before a pool
+        } else {
+            const int m = l - 1;   // the layer whose activation this gradient flows into
+            const Inject& in = inj[m];
+            if (in.S) {
+                ConvParams q{};
+                q.in = a.act[m]; q.wt = in.S; q.out = oth;
+                q.H = a.h[m]; q.W = a.w[m]; q.Cin = kCout[m]; q.Cout = kCout[m];
+                Timer t(ctx, s, K_GRAM, conv_flops(q.H, q.W, q.Cin, q.Cout, 1));
+                HIPCHK(ctx, launch_conv_mfma(q, 1, s));
+                p.addend = oth;
+            } else if (in.content && cj) {
+                Timer t(ctx, s, K_OTHER, 0);
+                HIPCHK(ctx, launch_mse_grad(a.act[m], cj->target, cj->n, cj->coef, oth, cj->partial, s));
+                p.addend = oth;
+            } else if (in.direct) {
+                p.addend = in.direct;
+            }
+            p.mask = a.act[m];
+            {
+                Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9));
+                HIPCHK(ctx, launch_conv_mfma(p, 9, s));
+            }
+            float* tmp = cur; cur = oth; oth = tmp;
+        }
+    }
+    {
+        Timer t(ctx, s, K_CONV1, conv_flops(h, w, 64, 3, 9));
+        HIPCHK(ctx, launch_conv1_1_dgrad(cur, h, w, ctx->w11d, gx, s));
+    }
+    return NST_OK;
+}
+
+int gram_of(nst_ctx* ctx, const float* f_nhwc, size_t N, int C, float divisor, float* part, const float* target,
+            float coef, float* gram_out, float* S, double* mse_partial, hipStream_t s) {
+    const int ns = gram_nsplit(C, N);
+    {
+        Timer t(ctx, s, K_GRAM, 2.0 * (double)N * C * C);
+        HIPCHK(ctx, launch_gram_partial(f_nhwc, N, C, ns, part, s));
+    }
+    Timer t(ctx, s, K_OTHER, 0);
+    HIPCHK(ctx, launch_gram_finish(part, gram_nslabs(C, ns), C, divisor, target, coef, gram_out, S, mse_partial, s));
+    return NST_OK;
+}
+
+size_t gram_part_floats_for(int h, int w) {
+    size_t mx = 0;
+    for (int k = 0; k < 5; ++k) {
+        const int l = kStyleLayer[k];
+        const size_t N = (size_t)(h >> kScale[l]) * (w >> kScale[l]);
+        const size_t f = (size_t)gram_nsplit(kCout[l], N) * kCout[l] * kCout[l];
+        if (f > mx) mx = f;
+    }
+    return mx;
+}
+
+void free_level(nst_ctx* ctx, LevelWs& L) {
+    free_acts(ctx, L.acts);
+    dev_free(L.gbuf[0]); dev_free(L.gbuf[1]); dev_free(L.xl); dev_free(L.gxl); dev_free(L.content_t);
+    for (int k = 0; k < 5; ++k) { dev_free(L.gram_t[k]); dev_free(L.S[k]); dev_free(L.style_partial[k]); }
+    dev_free(L.gram_part); dev_free(L.content_partial); dev_free(L.tv_partial); dev_free(L.tv_means);
+    if (L.stream) (void)hipStreamDestroy(L.stream);
+    if (L.done) (void)hipEventDestroy(L.done);
+    L = LevelWs();
+}
+
+int bind(nst_ctx* ctx) {
+    if (!ctx) return fail(nullptr, NST_E_ARG, "null context");
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    return NST_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int nst_version(void) { return 100; }
+
+const char* nst_last_error(const nst_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int nst_device_count(int* count) {
+    if (!count) return fail(nullptr, NST_E_ARG, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(nullptr, NST_E_HIP, hipGetErrorString(e)); }
+    *count = n;
+    return NST_OK;
+}
+
+int nst_ctx_create(int device, const float* const* weights, const float* const* biases, nst_ctx** out) {
+    if (!weights || !biases || !out) return fail(nullptr, NST_E_ARG, "null argument");
+    for (int l = 0; l < NL; ++l)
+        if (!weights[l] || !biases[l]) return fail(nullptr, NST_E_ARG, "null weight/bias pointer");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(nullptr, NST_E_HIP, "no HIP device visible");
+    if (device < 0 || device >= ndev) return fail(nullptr, NST_E_ARG, "device index out of range");
+    nst_ctx* ctx = new (std::nothrow) nst_ctx();
+    if (!ctx) return fail(nullptr, NST_E_NOMEM, "out of host memory");
+    ctx->device = device;
+    auto bail = [&](int code) { g_err = ctx->err; nst_ctx_destroy(ctx); return code; };
+    if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(NST_E_HIP); }
+    hipError_t e = conv_mfma_init_device();
+    if (e == hipSuccess) e = gram_init_device();
+    if (e != hipSuccess) { ctx->err = std::string("kernel attribute setup: ") + hipGetErrorString(e); return bail(NST_E_HIP); }
+    const char* ss = getenv("NST_SINGLE_STREAM");
+    ctx->single_stream = ss && ss[0] == '1';
+
+    std::vector<float> tmp;
+    for (int l = 0; l < NL; ++l) {
+        const int ci = kCin[l], co = kCout[l];
+        const float* W = weights[l];   // [co][ci][3][3]
+        if (dev_alloc_t(ctx, &ctx->bias[l], co) != NST_OK) return bail(NST_E_NOMEM);
+        if (hipMemcpy(ctx->bias[l], biases[l], co * 4, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "bias upload failed"; return bail(NST_E_HIP); }
+        if (l == 0) {
+            tmp.assign(28 * 64, 0.f);
+            for (int o = 0; o < 64; ++o)
+                for (int c = 0; c < 3; ++c)
+                    for (int t = 0; t < 9; ++t) tmp[(c * 9 + t) * 64 + o] = W[(o * 3 + c) * 9 + t];
+            if (dev_alloc_t(ctx, &ctx->w11k, tmp.size()) != NST_OK) return bail(NST_E_NOMEM);
+            if (hipMemcpy(ctx->w11k, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+            tmp.assign(9 * 64 * 4, 0.f);
+            for (int t = 0; t < 9; ++t) {
+                const int ky = 2 - t / 3, kx = 2 - t % 3;
+                for (int o = 0; o < 64; ++o)
+                    for (int c = 0; c < 3; ++c) tmp[(t * 64 + o) * 4 + c] = W[(o * 3 + c) * 9 + ky * 3 + kx];
+            }
+            if (dev_alloc_t(ctx, &ctx->w11d, tmp.size()) != NST_OK) return bail(NST_E_NOMEM);
+            if (hipMemcpy(ctx->w11d, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+            continue;
+        }
+        const size_t n = (size_t)9 * ci * co;
+        tmp.resize(n);
+        // forward: wf[tap][co][ci]
+        for (int t = 0; t < 9; ++t)
+            for (int o = 0; o < co; ++o)
+                for (int c = 0; c < ci; ++c) tmp[((size_t)t * co + o) * ci + c] = W[((size_t)o * ci + c) * 9 + t];
+        if (dev_alloc_t(ctx, &ctx->wf[l], n) != NST_OK) return bail(NST_E_NOMEM);
+        if (hipMemcpy(ctx->wf[l], tmp.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+        // input gradient: a conv with "Cout" = ci and "Cin" = co: wd[tap'][ci][co] = W[co][ci][2-ky'][2-kx']
+        for (int t = 0; t < 9; ++t) {
+            const int ky = 2 - t / 3, kx = 2 - t % 3;
+            for (int c = 0; c < ci; ++c)
+                for (int o = 0; o < co; ++o) tmp[((size_t)t * ci + c) * co + o] = W[((size_t)o * ci + c) * 9 + ky * 3 + kx];
+        }
+        if (dev_alloc_t(ctx, &ctx->wd[l], n) != NST_OK) return bail(NST_E_NOMEM);
+        if (hipMemcpy(ctx->wd[l], tmp.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+    }
+    if (hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
+        ctx->err = "event creation failed";
+        return bail(NST_E_HIP);
+    }
+    *out = ctx;
+    return NST_OK;
+}
+
+void nst_ctx_destroy(nst_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < NST_MAX_LEVELS; ++i) free_level(ctx, ctx->lv[i]);
+    for (int l = 0; l < NL; ++l) { dev_free(ctx->wf[l]); dev_free(ctx->wd[l]); dev_free(ctx->bias[l]); }
+    dev_free(ctx->w11k); dev_free(ctx->w11d);
+    if (ctx->fork) (void)hipEventDestroy(ctx->fork);
+    if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+    if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    delete ctx;
+}
+
+int nst_ctx_bytes(const nst_ctx* ctx, size_t* bytes) {
+    if (!ctx || !bytes) return fail(nullptr, NST_E_ARG, "null argument");
+    *bytes = ctx->bytes;
+    return NST_OK;
+}
+
+int nst_job_configure(nst_ctx* ctx, int levels_num, int H0, int W0) {
+    NSTCHK(bind(ctx));
+    if (levels_num < 1 || levels_num > NST_MAX_LEVELS) return fail(ctx, NST_E_ARG, "levels_num out of range");
+    if ((H0 >> (levels_num - 1)) < 16 || (W0 >> (levels_num - 1)) < 16)
+        return fail(ctx, NST_E_ARG, "coarsest pyramid level must be at least 16x16");
+    HIPCHK(ctx, hipDeviceSynchronize());
+    for (int i = 0; i < NST_MAX_LEVELS; ++i) free_level(ctx, ctx->lv[i]);
+    ctx->levels = 0;
+    int h = H0, w = W0;
+    for (int i = 0; i < levels_num; ++i) {
+        LevelWs& L = ctx->lv[i];
+        L.h = h; L.w = w;
+        NSTCHK(alloc_acts(ctx, L.acts, h, w));
+        L.gbuf_floats = (size_t)h * w * 64;
+        NSTCHK(dev_alloc_t(ctx, &L.gbuf[0], L.gbuf_floats));
+        NSTCHK(dev_alloc_t(ctx, &L.gbuf[1], L.gbuf_floats));
+        if (i > 0) {
+            NSTCHK(dev_alloc_t(ctx, &L.xl, (size_t)3 * h * w));
+            NSTCHK(dev_alloc_t(ctx, &L.gxl, (size_t)3 * h * w));
+        }
+        L.content_n = (size_t)L.acts.h[kContentLayer] * L.acts.w[kContentLayer] * kCout[kContentLayer];
+        NSTCHK(dev_alloc_t(ctx, &L.content_t, L.content_n));
+        for (int k = 0; k < 5; ++k) {
+            const int C = kCout[kStyleLayer[k]];
+            NSTCHK(dev_alloc_t(ctx, &L.gram_t[k], (size_t)C * C));
+            NSTCHK(dev_alloc_t(ctx, &L.S[k], (size_t)C * C));
+            NSTCHK(dev_alloc_t(ctx, &L.style_partial[k], GRAM_FIN_BLOCKS));
+        }
+        L.gram_part_floats = gram_part_floats_for(h, w);
+        NSTCHK(dev_alloc_t(ctx, &L.gram_part, L.gram_part_floats));
+        NSTCHK(dev_alloc_t(ctx, &L.content_partial, MSE_BLOCKS));
+        NSTCHK(dev_alloc_t(ctx, &L.tv_partial, 2 * TV_BLOCKS));
+        NSTCHK(dev_alloc_t(ctx, &L.tv_means, 2));
+        HIPCHK(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        HIPCHK(ctx, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        h /= 2; w /= 2;
+    }
+    ctx->levels = levels_num;
+    return NST_OK;
+}
+
+int nst_level_set_targets(nst_ctx* ctx, int level, const float* content, const float* style, int hs, int ws,
+                          void* stream) {
+    NSTCHK(bind(ctx));
+    if (level < 0 || level >= ctx->levels) return fail(ctx, NST_E_STATE, "level not configured");
+    if (!content || !style) return fail(ctx, NST_E_ARG, "null image");
+    if (hs < 16 || ws < 16) return fail(ctx, NST_E_ARG, "style image must be at least 16x16");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LevelWs& L = ctx->lv[level];
+    // content: ReLU(conv4_2) of the content image, through the level's own activation buffers
+    NSTCHK(forward(ctx, L.acts, content, L.h, L.w, s, kContentLayer));
+    HIPCHK(ctx, hipMemcpyAsync(L.content_t, L.acts.act[kContentLayer], L.content_n * 4, hipMemcpyDeviceToDevice, s));
+    // style: 5 Gram matrices of the style image (its own size)
+    ActSet sa;
+    int r = alloc_acts(ctx, sa, hs, ws);
+    float* part = nullptr;
+    if (r == NST_OK) r = dev_alloc_t(ctx, &part, gram_part_floats_for(hs, ws));
+    if (r == NST_OK) r = forward(ctx, sa, style, hs, ws, s);
+    for (int k = 0; k < 5 && r == NST_OK; ++k) {
+        const int l = kStyleLayer[k];
+        const int C = kCout[l];
+        const size_t N = (size_t)sa.h[l] * sa.w[l];
+        r = gram_of(ctx, sa.act[l], N, C, (float)((double)C * sa.h[l] * sa.w[l]), part, nullptr, 0.f, L.gram_t[k],
+                    nullptr, nullptr, s);
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    free_acts(ctx, sa);
+    dev_free(part);
+    if (r != NST_OK) return r;
+    HIPCHK(ctx, e);
+    L.targets = true;
+    return NST_OK;
+}
+
+int nst_set_timing(nst_ctx* ctx, int enabled) {
+    NSTCHK(bind(ctx));
+    ctx->timing = enabled;
+    if (enabled >= 2 && ctx->ev_pool.empty()) {
+        ctx->ev_pool.resize(2048);
+        for (auto& e : ctx->ev_pool) HIPCHK(ctx, hipEventCreate(&e));
+    }
+    return NST_OK;
+}
+
+int nst_closure(nst_ctx* ctx, const float* x, float cw, float sw, float tvw, float* grad, float* losses, void* stream) {
+    NSTCHK(bind(ctx));
+    if (ctx->levels < 1) return fail(ctx, NST_E_STATE, "nst_job_configure has not been called");
+    if (!x || !grad || !losses) return fail(ctx, NST_E_ARG, "null buffer");
+    for (int i = 0; i < ctx->levels; ++i)
+        if (!ctx->lv[i].targets) return fail(ctx, NST_E_STATE, "targets of level " + std::to_string(i) + " not set");
+    hipStream_t main = static_cast<hipStream_t>(stream);
+    ctx->timed.clear();
+    ctx->ev_used = 0;
+    ctx->timed_valid = false;
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->t0, main));
+
+    // pyramid of the optimised image (neural_style_transfer.py:170-176)
+    const float* xi[NST_MAX_LEVELS];
+    float* gi[NST_MAX_LEVELS];
+    xi[0] = x; gi[0] = grad;
+    for (int i = 1; i < ctx->levels; ++i) {
+        LevelWs& L = ctx->lv[i];
+        Timer t(ctx, main, K_OTHER, 0);
+        HIPCHK(ctx, launch_bicubic_down(xi[i - 1], 3, ctx->lv[i - 1].h, ctx->lv[i - 1].w, L.h, L.w, L.xl, main));
+        xi[i] = L.xl; gi[i] = L.gxl;
+    }
+    const bool multi = !ctx->single_stream && ctx->levels > 1;
+    if (multi) HIPCHK(ctx, hipEventRecord(ctx->fork, main));
+
+    for (int i = 0; i < ctx->levels; ++i) {
+        LevelWs& L = ctx->lv[i];
+        hipStream_t s = multi ? L.stream : main;
+        if (multi) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->fork, 0));
+        {
+            Timer t(ctx, s, K_OTHER, 0);
+            HIPCHK(ctx, launch_tv_partial(xi[i], 3, L.h, L.w, L.tv_partial, s));
+        }
+        NSTCHK(forward(ctx, L.acts, xi[i], L.h, L.w, s));
+        Inject inj[NL];
+        for (int k = 0; k < 5; ++k) {
+            const int l = kStyleLayer[k];
+            const int C = kCout[l];
+            const size_t N = (size_t)L.acts.h[l] * L.acts.w[l];
+            const double chw = (double)C * (double)N;
+            // style = mean_k mse(G_k, Gt_k); dL/dG = sw/5 * 2 (G-Gt)/C^2; dF = 2 * dL/dG * F / (C h w)
+            const float coef = (float)((double)sw * 4.0 / (5.0 * (double)C * C * chw));
+            NSTCHK(gram_of(ctx, L.acts.act[l], N, C, (float)chw, L.gram_part, L.gram_t[k], coef, nullptr, L.S[k],
+                           L.style_partial[k], s));
+            inj[l].S = L.S[k];
+        }
+        inj[kContentLayer].content = true;
+        ContentJob cj{L.content_t, L.content_n, (float)((double)cw * 2.0 / (double)L.content_n), L.content_partial};
+        NSTCHK(backward(ctx, L.acts, inj, &cj, L.gbuf[0], L.gbuf[1], gi[i], L.h, L.w, s));
+        {
+            Timer t(ctx, s, K_OTHER, 0);
+            HIPCHK(ctx, launch_tv_finish(xi[i], 3, L.h, L.w, L.tv_partial, tvw, gi[i], 1, L.tv_means, s));
+        }
+        if (multi) HIPCHK(ctx, hipEventRecord(L.done, s));
+    }
+    if (multi)
+        for (int i = 0; i < ctx->levels; ++i) HIPCHK(ctx, hipStreamWaitEvent(main, ctx->lv[i].done, 0));
+
+    // pull the coarse-level gradients back up the bicubic chain (autograd of :173-176)
+    for (int i = ctx->levels - 1; i >= 1; --i) {
+        Timer t(ctx, main, K_OTHER, 0);
+        HIPCHK(ctx, launch_bicubic_down_bwd(gi[i], 3, ctx->lv[i - 1].h, ctx->lv[i - 1].w, ctx->lv[i].h, ctx->lv[i].w,
+                                            gi[i - 1], 1, main));
+    }
+    LossAssembly la{};
+    la.levels = ctx->levels; la.cw = cw; la.sw = sw; la.tvw = tvw; la.out = losses;
+    for (int i = 0; i < ctx->levels; ++i) {
+        LevelWs& L = ctx->lv[i];
+        la.lv[i].content_partial = L.content_partial;
+        la.lv[i].content_n = L.content_n;
+        for (int k = 0; k < 5; ++k) { la.lv[i].style_partial[k] = L.style_partial[k]; la.lv[i].style_c[k] = kCout[kStyleLayer[k]]; }
+        la.lv[i].tv_means = L.tv_means;
+    }
+    HIPCHK(ctx, launch_loss_assemble(la, main));
+    if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->t1, main)); ctx->timed_valid = true; }
+    return NST_OK;
+}
+
+int nst_last_closure_ms(nst_ctx* ctx, float* ms) {
+    NSTCHK(bind(ctx));
+    if (!ms) return fail(ctx, NST_E_ARG, "null argument");
+    *ms = 0.f;
+    if (!ctx->timed_valid) return NST_OK;
+    HIPCHK(ctx, hipEventSynchronize(ctx->t1));
+    HIPCHK(ctx, hipEventElapsedTime(ms, ctx->t0, ctx->t1));
+    return NST_OK;
+}
+
+// per kernel class of the last closure: summed launch durations (ms), launch count, algorithmic flops
+int nst_last_closure_class(nst_ctx* ctx, int cls, float* ms, int* launches, double* flops) {
+    NSTCHK(bind(ctx));
+    if (!ms || !launches || !flops || cls < 0 || cls >= K_NCLASS) return fail(ctx, NST_E_ARG, "bad argument");
+    *ms = 0.f; *launches = 0; *flops = 0.0;
+    if (!ctx->timed_valid) return NST_OK;
+    HIPCHK(ctx, hipEventSynchronize(ctx->t1));
+    for (const TimedLaunch& t : ctx->timed) {
+        if (t.cls != cls) continue;
+        float d = 0.f;
+        HIPCHK(ctx, hipEventSynchronize(t.b));
+        HIPCHK(ctx, hipEventElapsedTime(&d, t.a, t.b));
+        *ms += d; *launches += 1; *flops += t.flops;
+    }
+    return NST_OK;
+}
+
+// ---- standalone pieces -----------------------------------------------------------------------------
+int nst_vgg_features(nst_ctx* ctx, const float* x, int h, int w, float* const* outs, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!x || !outs) return fail(ctx, NST_E_ARG, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ActSet a;
+    int r = alloc_acts(ctx, a, h, w);
+    if (r == NST_OK) r = forward(ctx, a, x, h, w, s);
+    for (int i = 0; i < 6 && r == NST_OK; ++i) {
+        if (!outs[i]) continue;
+        const int l = kTapLayer[i];
+        if (launch_hwc_to_chw(a.act[l], kCout[l], a.h[l], a.w[l], outs[i], s) != hipSuccess) r = fail(ctx, NST_E_HIP, "hwc_to_chw launch failed");
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    free_acts(ctx, a);
+    if (r != NST_OK) return r;
+    HIPCHK(ctx, e);
+    return NST_OK;
+}
+
+int nst_vgg_features_backward(nst_ctx* ctx, const float* x, int h, int w, const float* const* gouts, float* gx,
+                              void* stream) {
+    NSTCHK(bind(ctx));
+    if (!x || !gouts || !gx) return fail(ctx, NST_E_ARG, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ActSet a;
+    float* g0 = nullptr; float* g1 = nullptr;
+    float* inj_buf[6] = {};
+    int r = alloc_acts(ctx, a, h, w);
+    if (r == NST_OK) r = dev_alloc_t(ctx, &g0, (size_t)h * w * 64);
+    if (r == NST_OK) r = dev_alloc_t(ctx, &g1, (size_t)h * w * 64);
+    if (r == NST_OK) r = forward(ctx, a, x, h, w, s);
+    Inject inj[NL];
+    for (int i = 0; i < 6 && r == NST_OK; ++i) {
+        if (!gouts[i]) continue;
+        const int l = kTapLayer[i];
+        r = dev_alloc_t(ctx, &inj_buf[i], (size_t)a.h[l] * a.w[l] * kCout[l]);
+        if (r == NST_OK && launch_chw_to_hwc(gouts[i], kCout[l], a.h[l], a.w[l], inj_buf[i], s) != hipSuccess)
+            r = fail(ctx, NST_E_HIP, "chw_to_hwc launch failed");
+        inj[l].direct = inj_buf[i];
+    }
+    if (r == NST_OK) r = backward(ctx, a, inj, nullptr, g0, g1, gx, h, w, s);
+    hipError_t e = hipStreamSynchronize(s);
+    free_acts(ctx, a);
+    dev_free(g0); dev_free(g1);
+    for (int i = 0; i < 6; ++i) dev_free(inj_buf[i]);
+    if (r != NST_OK) return r;
+    HIPCHK(ctx, e);
+    return NST_OK;
+}
+
+int nst_gram(nst_ctx* ctx, const float* f, int C, int h, int w, int normalize, float* gram, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!f || !gram || C < 1 || h < 1 || w < 1) return fail(ctx, NST_E_ARG, "bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t N = (size_t)h * w;
+    float* nhwc = nullptr; float* part = nullptr;
+    int r = dev_alloc_t(ctx, &nhwc, N * C);
+    if (r == NST_OK) r = dev_alloc_t(ctx, &part, (size_t)gram_nsplit(C, N) * C * C);
+    if (r == NST_OK && launch_chw_to_hwc(f, C, h, w, nhwc, s) != hipSuccess) r = fail(ctx, NST_E_HIP, "chw_to_hwc launch failed");
+    if (r == NST_OK)
+        r = gram_of(ctx, nhwc, N, C, normalize ? (float)((double)C * h * w) : 1.f, part, nullptr, 0.f, gram, nullptr, nullptr, s);
+    hipError_t e = hipStreamSynchronize(s);
+    dev_free(nhwc); dev_free(part);
+    if (r != NST_OK) return r;
+    HIPCHK(ctx, e);
+    return NST_OK;
+}
+
+int nst_total_variation(nst_ctx* ctx, const float* y, int C, int h, int w, float* value, float* grad, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!y || !value) return fail(ctx, NST_E_ARG, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    double* partial = nullptr; float* means = nullptr;
+    int r = dev_alloc_t(ctx, &partial, 2 * TV_BLOCKS);
+    if (r == NST_OK) r = dev_alloc_t(ctx, &means, 2);
+    hipError_t e = hipSuccess;
+    if (r == NST_OK) {
+        e = launch_tv_partial(y, C, h, w, partial, s);
+        if (e == hipSuccess) e = launch_tv_finish(y, C, h, w, partial, 1.f, grad, 0, means, s);
+        float m[2] = {0, 0};
+        if (e == hipSuccess) e = hipMemcpyAsync(m, means, 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        const float tv = m[0] * m[0] + m[1] * m[1];
+        if (e == hipSuccess) e = hipMemcpy(value, &tv, 4, hipMemcpyHostToDevice);
+    }
+    dev_free(partial); dev_free(means);
+    if (r != NST_OK) return r;
+    HIPCHK(ctx, e);
+    return NST_OK;
+}
+
+int nst_bicubic_half(nst_ctx* ctx, const float* x, int C, int h, int w, float* y, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!x || !y || h < 2 || w < 2) return fail(ctx, NST_E_ARG, "bad argument");
+    HIPCHK(ctx, launch_bicubic_down(x, C, h, w, h / 2, w / 2, y, static_cast<hipStream_t>(stream)));
+    return NST_OK;
+}
+int nst_bicubic_half_backward(nst_ctx* ctx, const float* gy, int C, int h, int w, float* gx, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!gy || !gx || h < 2 || w < 2) return fail(ctx, NST_E_ARG, "bad argument");
+    HIPCHK(ctx, launch_bicubic_down_bwd(gy, C, h, w, h / 2, w / 2, gx, 0, static_cast<hipStream_t>(stream)));
+    return NST_OK;
+}
+int nst_prepare_img(nst_ctx* ctx, const float* hwc, int h, int w, float* chw, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!hwc || !chw) return fail(ctx, NST_E_ARG, "null argument");
+    HIPCHK(ctx, launch_prepare_img(hwc, h, w, chw, static_cast<hipStream_t>(stream)));
+    return NST_OK;
+}
+int nst_unprepare_img(nst_ctx* ctx, const float* chw, int h, int w, float* hwc, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!hwc || !chw) return fail(ctx, NST_E_ARG, "null argument");
+    HIPCHK(ctx, launch_unprepare_img(chw, h, w, hwc, static_cast<hipStream_t>(stream)));
+    return NST_OK;
+}
+
+// ---- internal accessors for nst_opt.cpp (not part of the public ABI) --------------------------------
+int nst_internal_device(const nst_ctx* ctx) { return ctx ? ctx->device : 0; }
+int nst_internal_levels(const nst_ctx* ctx) { return ctx ? ctx->levels : 0; }
+size_t nst_internal_pixels(const nst_ctx* ctx) { return (ctx && ctx->levels > 0) ? (size_t)ctx->lv[0].h * ctx->lv[0].w : 0; }
+int nst_internal_fail(nst_ctx* ctx, int code, const char* msg) { return fail(ctx, code, msg ? msg : ""); }
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+// nst_kernels.h - internal launch interface between the C-ABI layer (nst_api.cpp) and the
+// gfx950 kernels.  Activations inside the network are NHWC fp32 ("pixel-major": [y][x][C]);
+// the optimised image, its pyramid levels and their gradients are planar (3,h,w) fp32, the
+// storage of the torch tensor the reference optimises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace nst {
+
+struct ConvParams {
+    const float* in;      // [H][W][Cin]
+    const float* wt;      // [TAPS][Cout][Cin]
+    const float* bias;    // [Cout] or nullptr
+    const float* addend;  // [H][W][Cout] or nullptr (may alias out)
+    const float* mask;    // [H][W][Cout] or nullptr: out = mask > 0 ? v : 0
+    float* out;           // [H][W][Cout]
+    int H, W, Cin, Cout;
+    int relu;
+    int tiles_x, tiles_y; // filled by the launcher
+};
+
+// conv_mfma.hip
+hipError_t conv_mfma_init_device();
+hipError_t launch_conv_mfma(const ConvParams& p, int taps, hipStream_t stream);
+
+// conv_first.hip: conv1_1 (3 -> 64) forward from the planar image, and its input gradient
+// wk: [28][64] (k = c*9 + ky*3 + kx, row 27 zero); bias [64]; out NHWC 64, ReLU applied.
+hipError_t launch_conv1_1_fwd(const float* x, int H, int W, const float* wk, const float* bias, float* out,
+                              hipStream_t stream);
+// g: [H][W][64] gradient w.r.t. the pre-ReLU conv1_1 output; wd: [9][64][4] flipped taps
+// (wd[t][co][c] = W[co][c][2-ky][2-kx], c = 3 unused 0); gx planar (3,H,W), overwritten.
+hipError_t launch_conv1_1_dgrad(const float* g, int H, int W, const float* wd, float* gx, hipStream_t stream);
+
+// pixel_ops.hip ---------------------------------------------------------------------------------
+// 2x2/2 max pool (floor) over NHWC, C % 4 == 0
+hipError_t launch_maxpool_fwd(const float* in, int H, int W, int C, float* out, hipStream_t stream);
+// gin[y][x][c] = (a[y][x][c] is the first maximum of its window and a > 0) ? gpool[y/2][x/2][c] : 0
+// (max_pool2d backward fused with the ReLU mask of the activation `a` that was pooled)
+hipError_t launch_maxpool_bwd_relu(const float* a, const float* gpool, int H, int W, int C, float* gin,
+                                   hipStream_t stream);
+// planar (C,h,w) <-> NHWC
+hipError_t launch_chw_to_hwc(const float* src, int C, int H, int W, float* dst, hipStream_t stream);
+hipError_t launch_hwc_to_chw(const float* src, int C, int H, int W, float* dst, hipStream_t stream);
+// dst = (src > 0 ? g : 0) elementwise over n floats (n % 4 == 0)
+hipError_t launch_relu_mask(const float* act, const float* g, size_t n, float* dst, hipStream_t stream);
+// dst += src over n floats
+hipError_t launch_add_inplace(float* dst, const float* src, size_t n, hipStream_t stream);
+
+// general bicubic (A=-0.75, align_corners=False, clamped taps) down-sample of planar (C,h,w) to
+// (C,oh,ow) and its transpose; the pyramid uses oh=h/2, ow=w/2.
+hipError_t launch_bicubic_down(const float* x, int C, int h, int w, int oh, int ow, float* y, hipStream_t stream);
+// gx (C,h,w): accumulate != 0 -> gx += transpose(gy), else gx = transpose(gy)
+hipError_t launch_bicubic_down_bwd(const float* gy, int C, int h, int w, int oh, int ow, float* gx, int accumulate,
+                                   hipStream_t stream);
+
+// total variation: partial sums of |dx| and |dy| (NST_TV_BLOCKS x 2 doubles in `partial`)
+constexpr int TV_BLOCKS = 256;
+hipError_t launch_tv_partial(const float* y, int C, int h, int w, double* partial, hipStream_t stream);
+// reduces the partials (fixed order), writes means to scal[0..1]; if grad: grad (+)= weight * d tv/dy
+hipError_t launch_tv_finish(const float* y, int C, int h, int w, const double* partial, float weight, float* grad,
+                            int accumulate, float* means, hipStream_t stream);
+
+// content: sum((a - t)^2) partials and, if g != nullptr, g = coef * (a - t) (coef = cw*2/n)
+constexpr int MSE_BLOCKS = 256;
+hipError_t launch_mse_grad(const float* a, const float* t, size_t n, float coef, float* g, double* partial,
+                           hipStream_t stream);
+
+// prepare / unprepare
+hipError_t launch_prepare_img(const float* hwc, int h, int w, float* chw, hipStream_t stream);
+hipError_t launch_unprepare_img(const float* chw, int h, int w, float* hwc, hipStream_t stream);
+
+constexpr int GRAM_FIN_BLOCKS = 64;
+// loss assembly -----------------------------------------------------------------------------------
+struct LevelLossInputs {
+    const double* content_partial;   // MSE_BLOCKS doubles
+    size_t content_n;
+    const double* style_partial[5];  // GRAM_FIN_BLOCKS doubles each: partial sums of (G-Gt)^2
+    int style_c[5];                  // C of each style layer (mse mean over C*C)
+    const float* tv_means;           // 2 floats (mean_x, mean_y)
+};
+struct LossAssembly {
+    LevelLossInputs lv[8];
+    int levels;
+    float cw, sw, tvw;
+    float* out;                      // 4*levels + 1
+};
+hipError_t launch_loss_assemble(const LossAssembly& la, hipStream_t stream);
+
+// gram.hip -----------------------------------------------------------------------------------------
+// partial Gram of NHWC f (N pixels x C): slabs part[s][C][C] (upper-triangle tiles only)
+hipError_t gram_init_device();
+int gram_nsplit(int C, size_t N);
+hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, float* part, hipStream_t stream);
+// G = (sum_s part[s]) / divisor (fixed order).  If target: mse_out[0] = sum((G-Gt)^2) (double) and
+// S = coef * (G - Gt) (C x C, for the backward 1x1 conv).  gram_out / target / S / mse_partial nullable;
+// mse_partial: GRAM_FIN_BLOCKS doubles.  `nslabs` = gram_nslabs(C, nsplit).
+int gram_nslabs(int C, int nsplit);
+hipError_t launch_gram_finish(const float* part, int nslabs, int C, float divisor, const float* target, float coef,
+                              float* gram_out, float* S, double* mse_partial, hipStream_t stream);
+
+// vector_ops.hip: optimiser arithmetic over the n pixel floats ---------------------------------------
+constexpr int RED_BLOCKS = 256;
+// out[0] = sum(a*b) as float (double accumulation inside), deterministic two-stage
+hipError_t launch_dot(const float* a, const float* b, size_t n, double* scratch, float* out, hipStream_t stream);
+// out[0] = max|a|, out[1] = sum|a|
+hipError_t launch_absmax_abssum(const float* a, size_t n, double* scratch, float* out, hipStream_t stream);
+// y = alpha * x + beta * y'  variants
+hipError_t launch_axpy(float alpha, const float* x, float* y, size_t n, hipStream_t stream);               // y += alpha*x
+hipError_t launch_axpy_dev(const float* alpha_dev, float sign, const float* x, float* y, size_t n, hipStream_t stream);
+hipError_t launch_scale_copy(float alpha, const float* x, float* y, size_t n, hipStream_t stream);         // y = alpha*x
+hipError_t launch_sub(const float* a, const float* b, float* out, size_t n, hipStream_t stream);           // out = a-b
+hipError_t launch_adam(float* x, const float* g, float* m, float* v, size_t n, float beta1, float beta2, float eps,
+                       float step_size, float inv_sqrt_bc2, hipStream_t stream);
+
+}  // namespace nst

@@ -1,0 +1,379 @@
+// nst_opt.cpp - the two optimisers the reference constructs (neural_style_transfer.py:134-136)
+// driving nst_closure on the device-resident pixel buffer:
+//   Adam   torch:optim/adam.py:457-546  (single tensor, betas (0.9, 0.999), eps 1e-8)
+//   L-BFGS torch:optim/lbfgs.py:332-537 (max_iter 1, strong_wolfe, history 100, tolerance_grad 1e-7,
+//          tolerance_change 1e-9; max_eval is a parameter, see include/nst_hip.h)
+// including the closure's own `lr *= 0.999` (neural_style_transfer.py:155-158).
+// Vector arithmetic runs in vector_ops.hip; only scalars (loss, dots) come back to the host,
+// because L-BFGS' control flow is host-side scalar logic in the reference too.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nst_hip.h"
+#include "nst_kernels.h"
+
+using namespace nst;
+
+extern "C" int nst_internal_device(const nst_ctx* ctx);
+extern "C" int nst_internal_levels(const nst_ctx* ctx);
+extern "C" size_t nst_internal_pixels(const nst_ctx* ctx);
+extern "C" int nst_internal_fail(nst_ctx* ctx, int code, const char* msg);
+
+struct nst_opt {
+    nst_ctx* ctx = nullptr;
+    int kind = 0;
+    size_t n = 0;
+    int levels = 0;
+    double lr = 10.0;            // python float in the reference
+    int total_closures = 0;
+    // device
+    float* g = nullptr;          // gradient of the latest closure
+    float* losses = nullptr;     // 4*levels+1
+    double* scratch = nullptr;   // 2*RED_BLOCKS
+    float* scal = nullptr;       // 4 floats
+    // adam
+    float* m = nullptr; float* v = nullptr; int k = 0;
+    // lbfgs
+    int max_eval = 1;
+    int history = 100;
+    int n_iter = 0;
+    float* d = nullptr; float* prev_g = nullptr; float* xinit = nullptr; float* q = nullptr;
+    std::vector<float*> old_dirs, old_stps;
+    std::vector<float> ro;
+    std::vector<float*> spare;   // recycled history vectors
+    bool H_is_one = true; float H_diag = 1.f;
+    bool t_is_float = true;      // t held as fp32 tensor value vs python double
+    double t = 0.0;
+    bool have_prev = false;
+    // per-step outputs
+    std::vector<float> loss_rows;   // host copy of every closure's loss rows in this step
+};
+
+namespace {
+
+#define OHIP(o, expr)                                                                                \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess)                                                                        \
+            return nst_internal_fail((o)->ctx, NST_E_HIP, (std::string(#expr) + ": " + hipGetErrorString(_e)).c_str()); \
+    } while (0)
+#define OCHK(expr)                   \
+    do {                             \
+        int _r = (expr);             \
+        if (_r != NST_OK) return _r; \
+    } while (0)
+
+int oalloc(nst_opt* o, float** p, size_t n) {
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(p), n * sizeof(float));
+    if (e != hipSuccess) return nst_internal_fail(o->ctx, NST_E_NOMEM, "hipMalloc failed in optimiser");
+    return NST_OK;
+}
+
+// one closure evaluation at x: decays lr, fills o->g, returns the total loss (host) - synchronises
+int eval_closure(nst_opt* o, const float* x, float cw, float sw, float tvw, hipStream_t s, float* loss_out) {
+    o->lr *= 0.999;                                                          // neural_style_transfer.py:155-158
+    OCHK(nst_closure(o->ctx, x, cw, sw, tvw, o->g, o->losses, s));
+    const size_t row = (size_t)NST_LOSS_ROW * o->levels + 1;
+    const size_t off = o->loss_rows.size();
+    o->loss_rows.resize(off + row);
+    OHIP(o, hipMemcpyAsync(o->loss_rows.data() + off, o->losses, row * sizeof(float), hipMemcpyDeviceToHost, s));
+    OHIP(o, hipStreamSynchronize(s));
+    o->total_closures += 1;                                                  // :198
+    *loss_out = o->loss_rows[off + row - 1];
+    return NST_OK;
+}
+
+int dot(nst_opt* o, const float* a, const float* b, hipStream_t s, float* out) {
+    OHIP(o, launch_dot(a, b, o->n, o->scratch, o->scal, s));
+    OHIP(o, hipMemcpyAsync(out, o->scal, sizeof(float), hipMemcpyDeviceToHost, s));
+    OHIP(o, hipStreamSynchronize(s));
+    return NST_OK;
+}
+int absstats(nst_opt* o, const float* a, hipStream_t s, float* mx, float* sum) {
+    float r[2];
+    OHIP(o, launch_absmax_abssum(a, o->n, o->scratch, o->scal, s));
+    OHIP(o, hipMemcpyAsync(r, o->scal, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    OHIP(o, hipStreamSynchronize(s));
+    *mx = r[0]; *sum = r[1];
+    return NST_OK;
+}
+
+// torch:optim/lbfgs.py:12-37 on host scalars
+double cubic_interpolate(double x1, double f1, double g1, double x2, double f2, double g2, bool has_bounds,
+                         double lo, double hi) {
+    double xmin = has_bounds ? lo : std::min(x1, x2);
+    double xmax = has_bounds ? hi : std::max(x1, x2);
+    const double d1 = g1 + g2 - 3 * (f1 - f2) / (x1 - x2);
+    const double d2sq = d1 * d1 - g1 * g2;
+    if (d2sq >= 0) {
+        const double d2 = std::sqrt(d2sq);
+        double min_pos;
+        if (x1 <= x2) min_pos = x2 - (x2 - x1) * ((g2 + d2 - d1) / (g2 - g1 + 2 * d2));
+        else min_pos = x1 - (x1 - x2) * ((g1 + d2 - d1) / (g1 - g2 + 2 * d2));
+        return std::min(std::max(min_pos, xmin), xmax);
+    }
+    return (xmin + xmax) / 2.0;
+}
+
+struct LsResult { double t; float f; int evals; };
+
+// torch:optim/lbfgs.py:40-209.  Gradients of bracket points are never needed by the caller with
+// max_iter == 1 (only f, g.d and t are consumed), so no gradient clones are kept.
+int strong_wolfe(nst_opt* o, float* x, double t, float f, float gtd, int max_ls, float cw, float sw, float tvw,
+                 hipStream_t s, LsResult* res) {
+    const double c1 = 1e-4, c2 = 0.9, tol_change = 1e-9;
+    float d_norm, dsum;
+    OCHK(absstats(o, o->d, s, &d_norm, &dsum));
+    auto eval_at = [&](double tt, float* f_new, float* gtd_new) -> int {
+        // x = x_init + t*d ; closure ; (x restored by the caller at the end)
+        OHIP(o, hipMemcpyAsync(x, o->xinit, o->n * sizeof(float), hipMemcpyDeviceToDevice, s));
+        OHIP(o, launch_axpy((float)tt, o->d, x, o->n, s));
+        OCHK(eval_closure(o, x, cw, sw, tvw, s, f_new));
+        OCHK(dot(o, o->g, o->d, s, gtd_new));
+        return NST_OK;
+    };
+    float f_new, gtd_new;
+    OCHK(eval_at(t, &f_new, &gtd_new));
+    int evals = 1;
+    double t_prev = 0; float f_prev = f; float gtd_prev = gtd;
+    bool done = false;
+    int ls_iter = 0;
+    double br[2] = {0, 0}; float br_f[2] = {0, 0}; float br_gtd[2] = {0, 0};
+    int nbr = 0;
+    while (ls_iter < max_ls) {
+        if (f_new > (float)(f + (float)(c1 * t) * gtd) || (ls_iter > 1 && f_new >= f_prev)) {
+            br[0] = t_prev; br[1] = t; br_f[0] = f_prev; br_f[1] = f_new; br_gtd[0] = gtd_prev; br_gtd[1] = gtd_new; nbr = 2;
+            break;
+        }
+        if (std::fabs(gtd_new) <= -(float)c2 * gtd) {
+            br[0] = t; br_f[0] = f_new; br_gtd[0] = gtd_new; nbr = 1; done = true;
+            break;
+        }
+        if (gtd_new >= 0) {
+            br[0] = t_prev; br[1] = t; br_f[0] = f_prev; br_f[1] = f_new; br_gtd[0] = gtd_prev; br_gtd[1] = gtd_new; nbr = 2;
+            break;
+        }
+        const double min_step = t + 0.01 * (t - t_prev);
+        const double max_step = t * 10;
+        const double tmp = t;
+        t = cubic_interpolate(t_prev, f_prev, gtd_prev, t, f_new, gtd_new, true, min_step, max_step);
+        t_prev = tmp; f_prev = f_new; gtd_prev = gtd_new;
+        OCHK(eval_at(t, &f_new, &gtd_new));
+        evals += 1;
+        ls_iter += 1;
+    }
+    if (ls_iter == max_ls && nbr == 0) {
+        br[0] = 0; br[1] = t; br_f[0] = f; br_f[1] = f_new; br_gtd[0] = gtd; br_gtd[1] = gtd_new; nbr = 2;
+    }
+    bool insuf = false;
+    int low = (br_f[0] <= br_f[nbr - 1]) ? 0 : 1, high = 1 - low;
+    if (nbr == 1) { low = 0; high = 0; }
+    while (!done && ls_iter < max_ls) {
+        if (std::fabs(br[1] - br[0]) * d_norm < tol_change) break;
+        t = cubic_interpolate(br[0], br_f[0], br_gtd[0], br[1], br_f[1], br_gtd[1], false, 0, 0);
+        const double bmax = std::max(br[0], br[1]), bmin = std::min(br[0], br[1]);
+        const double eps = 0.1 * (bmax - bmin);
+        if (std::min(bmax - t, t - bmin) < eps) {
+            if (insuf || t >= bmax || t <= bmin) {
+                t = (std::fabs(t - bmax) < std::fabs(t - bmin)) ? bmax - eps : bmin + eps;
+                insuf = false;
+            } else {
+                insuf = true;
+            }
+        } else {
+            insuf = false;
+        }
+        OCHK(eval_at(t, &f_new, &gtd_new));
+        evals += 1;
+        ls_iter += 1;
+        if (f_new > (float)(f + (float)(c1 * t) * gtd) || f_new >= br_f[low]) {
+            br[high] = t; br_f[high] = f_new; br_gtd[high] = gtd_new;
+            low = (br_f[0] <= br_f[1]) ? 0 : 1; high = 1 - low;
+        } else {
+            if (std::fabs(gtd_new) <= -(float)c2 * gtd) {
+                done = true;
+            } else if (gtd_new * (br[high] - br[low]) >= 0) {
+                br[high] = br[low]; br_f[high] = br_f[low]; br_gtd[high] = br_gtd[low];
+            }
+            br[low] = t; br_f[low] = f_new; br_gtd[low] = gtd_new;
+        }
+    }
+    res->t = br[low]; res->f = br_f[low]; res->evals = evals;
+    return NST_OK;
+}
+
+int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t s, nst_step_info* info) {
+    const double lr = o->lr;                                     // read before the closure decays it (lbfgs.py:349)
+    float loss;
+    OCHK(eval_closure(o, x, cw, sw, tvw, s, &loss));
+    info->loss = loss;
+    float gmax, gsum;
+    OCHK(absstats(o, o->g, s, &gmax, &gsum));
+    if (gmax <= 1e-7f) { info->accepted = 0; info->t = 0.f; return NST_OK; }
+    o->n_iter += 1;
+    const size_t nb = o->n * sizeof(float);
+    if (o->n_iter == 1) {
+        OHIP(o, launch_scale_copy(-1.f, o->g, o->d, o->n, s));   // d = -g
+        for (float* p : o->old_dirs) o->spare.push_back(p);
+        for (float* p : o->old_stps) o->spare.push_back(p);
+        o->old_dirs.clear(); o->old_stps.clear(); o->ro.clear();
+        o->H_is_one = true; o->H_diag = 1.f;
+    } else {
+        // y = g - prev_g ; s = d * t
+        float* y; float* st;
+        auto take = [&](float** p) -> int {
+            if (!o->spare.empty()) { *p = o->spare.back(); o->spare.pop_back(); return NST_OK; }
+            return oalloc(o, p, o->n);
+        };
+        OCHK(take(&y)); OCHK(take(&st));
+        OHIP(o, launch_sub(o->g, o->prev_g, y, o->n, s));
+        OHIP(o, launch_scale_copy((float)o->t, o->d, st, o->n, s));
+        float ys;
+        OCHK(dot(o, y, st, s, &ys));
+        if (ys > 1e-10f) {
+            if ((int)o->old_dirs.size() == o->history) {
+                o->spare.push_back(o->old_dirs.front()); o->spare.push_back(o->old_stps.front());
+                o->old_dirs.erase(o->old_dirs.begin()); o->old_stps.erase(o->old_stps.begin()); o->ro.erase(o->ro.begin());
+            }
+            o->old_dirs.push_back(y); o->old_stps.push_back(st); o->ro.push_back(1.0f / ys);
+            float yy;
+            OCHK(dot(o, y, y, s, &yy));
+            o->H_diag = ys / yy; o->H_is_one = false;
+        } else {
+            o->spare.push_back(y); o->spare.push_back(st);
+        }
+        const int num_old = (int)o->old_dirs.size();
+        std::vector<float> al(num_old);
+        OHIP(o, launch_scale_copy(-1.f, o->g, o->q, o->n, s));   // q = -g
+        for (int i = num_old - 1; i >= 0; --i) {
+            float sq;
+            OCHK(dot(o, o->old_stps[i], o->q, s, &sq));
+            al[i] = sq * o->ro[i];
+            OHIP(o, launch_axpy(-al[i], o->old_dirs[i], o->q, o->n, s));
+        }
+        OHIP(o, launch_scale_copy(o->H_is_one ? 1.f : o->H_diag, o->q, o->d, o->n, s));   // d = r = q * H_diag
+        for (int i = 0; i < num_old; ++i) {
+            float yr;
+            OCHK(dot(o, o->old_dirs[i], o->d, s, &yr));
+            const float be = yr * o->ro[i];
+            OHIP(o, launch_axpy(al[i] - be, o->old_stps[i], o->d, o->n, s));
+        }
+    }
+    OHIP(o, hipMemcpyAsync(o->prev_g, o->g, nb, hipMemcpyDeviceToDevice, s));
+    o->have_prev = true;
+    double t;
+    if (o->n_iter == 1) {
+        const float inv = 1.0f / gsum;
+        t = (inv < 1.0f) ? (double)(inv * (float)lr) : lr;       // min(1., 1./|g|_1) * lr
+    } else {
+        t = lr;
+    }
+    float gtd;
+    OCHK(dot(o, o->g, o->d, s, &gtd));
+    info->accepted = 0; info->t = 0.f;
+    if (!(gtd > -1e-9f)) {
+        OHIP(o, hipMemcpyAsync(o->xinit, x, nb, hipMemcpyDeviceToDevice, s));
+        LsResult r;
+        OCHK(strong_wolfe(o, x, t, loss, gtd, o->max_eval - 1, cw, sw, tvw, s, &r));
+        t = r.t;
+        OHIP(o, hipMemcpyAsync(x, o->xinit, nb, hipMemcpyDeviceToDevice, s));
+        if (t != 0.0) OHIP(o, launch_axpy((float)t, o->d, x, o->n, s));
+        info->accepted = (t != 0.0) ? 1 : 0;
+        info->t = (float)t;
+    }
+    o->t = t;
+    return NST_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nst_opt_create(nst_ctx* ctx, int kind, float lr_start, int lbfgs_max_eval, nst_opt** out) {
+    if (!ctx || !out) return nst_internal_fail(ctx, NST_E_ARG, "null argument");
+    if (kind != NST_OPT_ADAM && kind != NST_OPT_LBFGS) return nst_internal_fail(ctx, NST_E_ARG, "Unknown optimizer");
+    if (nst_internal_levels(ctx) < 1) return nst_internal_fail(ctx, NST_E_STATE, "nst_job_configure has not been called");
+    if (hipSetDevice(nst_internal_device(ctx)) != hipSuccess) return nst_internal_fail(ctx, NST_E_HIP, "hipSetDevice failed");
+    nst_opt* o = new (std::nothrow) nst_opt();
+    if (!o) return nst_internal_fail(ctx, NST_E_NOMEM, "out of host memory");
+    o->ctx = ctx; o->kind = kind; o->lr = (double)lr_start;
+    o->levels = nst_internal_levels(ctx);
+    o->n = 3 * nst_internal_pixels(ctx);
+    o->max_eval = lbfgs_max_eval < 1 ? 1 : lbfgs_max_eval;
+    int r = oalloc(o, &o->g, o->n);
+    if (r == NST_OK) r = oalloc(o, &o->losses, (size_t)NST_LOSS_ROW * o->levels + 1);
+    if (r == NST_OK) r = oalloc(o, &o->scal, 4);
+    if (r == NST_OK && hipMalloc(reinterpret_cast<void**>(&o->scratch), 2 * RED_BLOCKS * sizeof(double)) != hipSuccess) r = NST_E_NOMEM;
+    if (r == NST_OK && kind == NST_OPT_ADAM) {
+        r = oalloc(o, &o->m, o->n);
+        if (r == NST_OK) r = oalloc(o, &o->v, o->n);
+        if (r == NST_OK && (hipMemset(o->m, 0, o->n * 4) != hipSuccess || hipMemset(o->v, 0, o->n * 4) != hipSuccess)) r = NST_E_HIP;
+    }
+    if (r == NST_OK && kind == NST_OPT_LBFGS) {
+        r = oalloc(o, &o->d, o->n);
+        if (r == NST_OK) r = oalloc(o, &o->prev_g, o->n);
+        if (r == NST_OK) r = oalloc(o, &o->xinit, o->n);
+        if (r == NST_OK) r = oalloc(o, &o->q, o->n);
+    }
+    if (r != NST_OK) { nst_opt_destroy(o); return nst_internal_fail(ctx, r, "optimiser allocation failed"); }
+    *out = o;
+    return NST_OK;
+}
+
+void nst_opt_destroy(nst_opt* o) {
+    if (!o) return;
+    (void)hipSetDevice(nst_internal_device(o->ctx));
+    (void)hipDeviceSynchronize();
+    float* ptrs[] = {o->g, o->losses, o->scal, o->m, o->v, o->d, o->prev_g, o->xinit, o->q};
+    for (float* p : ptrs) if (p) (void)hipFree(p);
+    if (o->scratch) (void)hipFree(o->scratch);
+    for (float* p : o->old_dirs) (void)hipFree(p);
+    for (float* p : o->old_stps) (void)hipFree(p);
+    for (float* p : o->spare) (void)hipFree(p);
+    delete o;
+}
+
+int nst_opt_step(nst_opt* o, float* x, float cw, float sw, float tvw, float* losses_host, int closures_capacity,
+                 nst_step_info* info, void* stream) {
+    if (!o || !x || !info) return nst_internal_fail(o ? o->ctx : nullptr, NST_E_ARG, "null argument");
+    if (hipSetDevice(nst_internal_device(o->ctx)) != hipSuccess) return nst_internal_fail(o->ctx, NST_E_HIP, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::memset(info, 0, sizeof(*info));
+    o->loss_rows.clear();
+    const int before = o->total_closures;
+    if (o->kind == NST_OPT_ADAM) {
+        float loss = NAN;
+        if (losses_host) {
+            OCHK(eval_closure(o, x, cw, sw, tvw, s, &loss));
+        } else {
+            o->lr *= 0.999;
+            OCHK(nst_closure(o->ctx, x, cw, sw, tvw, o->g, o->losses, s));
+            o->total_closures += 1;
+        }
+        o->k += 1;
+        const double bc1 = 1.0 - std::pow(0.9, o->k);
+        const double bc2 = 1.0 - std::pow(0.999, o->k);
+        const double step_size = o->lr / bc1;                    // lr already decayed by the closure
+        OHIP(o, launch_adam(x, o->g, o->m, o->v, o->n, 0.9f, 0.999f, 1e-8f, (float)step_size, (float)std::sqrt(bc2), s));
+        info->loss = loss; info->accepted = 1; info->t = (float)step_size;
+    } else {
+        OCHK(lbfgs_step(o, x, cw, sw, tvw, s, info));
+    }
+    info->closures = o->total_closures - before;
+    info->total_closures = o->total_closures;
+    info->lr = (float)o->lr;
+    if (losses_host) {
+        const size_t row = (size_t)NST_LOSS_ROW * o->levels + 1;
+        const size_t have = o->loss_rows.size() / row;
+        const size_t cp = std::min(have, (size_t)std::max(closures_capacity, 0));
+        std::memcpy(losses_host, o->loss_rows.data(), cp * row * sizeof(float));
+    }
+    return NST_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,158 @@
+// vector_ops.hip - the optimiser's arithmetic over the n = 3*H0*W0 pixel floats: Adam
+// (torch:optim/adam.py:457-546) and the dots / axpys of L-BFGS (torch:optim/lbfgs.py:396-488).
+// All HBM-bound streaming kernels with 16-byte accesses; reductions are two-stage and ordered.
+#include <hip/hip_runtime.h>
+
+#include "nst_kernels.h"
+
+namespace nst {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int vblocks(size_t n4) {
+    size_t b = (n4 + 255) / 256;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+__device__ __forceinline__ double vblock_sum(double v, double* sh) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (threadIdx.x == 0) r = ((sh[0] + sh[1]) + sh[2]) + sh[3];
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float vblock_max(float v, float* sh) {
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_down(v, off, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    __syncthreads();
+    return r;
+}
+
+// ---- dot ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          size_t n, double* __restrict__ scratch) {
+    __shared__ double sh[4];
+    const size_t n4 = n / 4;
+    const f32x4* av = reinterpret_cast<const f32x4*>(a);
+    const f32x4* bv = reinterpret_cast<const f32x4*>(b);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 x = av[i], y = bv[i];
+        s0 += x[0] * y[0]; s1 += x[1] * y[1]; s2 += x[2] * y[2]; s3 += x[3] * y[3];
+    }
+    double s = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = n4 * 4; i < n; ++i) s += (double)a[i] * (double)b[i];
+    const double r = vblock_sum(s, sh);
+    if (threadIdx.x == 0) scratch[blockIdx.x] = r;
+}
+__global__ __launch_bounds__(256) void sum_finish_kernel(const double* __restrict__ scratch, float* __restrict__ out) {
+    __shared__ double sh[4];
+    const double r = vblock_sum(threadIdx.x < RED_BLOCKS ? scratch[threadIdx.x] : 0.0, sh);
+    if (threadIdx.x == 0) out[0] = (float)r;
+}
+hipError_t launch_dot(const float* a, const float* b, size_t n, double* scratch, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, stream, a, b, n, scratch);
+    hipLaunchKernelGGL(sum_finish_kernel, dim3(1), dim3(256), 0, stream, scratch, out);
+    return hipGetLastError();
+}
+
+// ---- max|a| and sum|a| ----------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void abs_partial_kernel(const float* __restrict__ a, size_t n,
+                                                          double* __restrict__ scratch) {
+    __shared__ double sh[4];
+    __shared__ float shm[4];
+    float mx = 0.f, s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = fabsf(a[i]);
+        mx = fmaxf(mx, v);
+        s += v;
+    }
+    const double rs = vblock_sum((double)s, sh);
+    const float rm = vblock_max(mx, shm);
+    if (threadIdx.x == 0) {
+        scratch[blockIdx.x] = rs;
+        scratch[RED_BLOCKS + blockIdx.x] = (double)rm;
+    }
+}
+__global__ __launch_bounds__(256) void abs_finish_kernel(const double* __restrict__ scratch, float* __restrict__ out) {
+    __shared__ double sh[4];
+    __shared__ float shm[4];
+    const double rs = vblock_sum(threadIdx.x < RED_BLOCKS ? scratch[threadIdx.x] : 0.0, sh);
+    const float rm = vblock_max(threadIdx.x < RED_BLOCKS ? (float)scratch[RED_BLOCKS + threadIdx.x] : 0.f, shm);
+    if (threadIdx.x == 0) { out[0] = rm; out[1] = (float)rs; }
+}
+hipError_t launch_absmax_abssum(const float* a, size_t n, double* scratch, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(abs_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, stream, a, n, scratch);
+    hipLaunchKernelGGL(abs_finish_kernel, dim3(1), dim3(256), 0, stream, scratch, out);
+    return hipGetLastError();
+}
+
+// ---- axpy family ----------------------------------------------------------------------------------
+__global__ void axpy_kernel(float alpha, const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = y[i] + alpha * x[i];
+}
+__global__ void axpy_dev_kernel(const float* __restrict__ alpha_dev, float sign, const float* __restrict__ x,
+                                float* __restrict__ y, size_t n) {
+    const float alpha = sign * alpha_dev[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = y[i] + alpha * x[i];
+}
+__global__ void scale_copy_kernel(float alpha, const float* __restrict__ x, float* __restrict__ y, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = alpha * x[i];
+}
+__global__ void sub_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = a[i] - b[i];
+}
+hipError_t launch_axpy(float alpha, const float* x, float* y, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(axpy_kernel, dim3(vblocks(n)), dim3(256), 0, stream, alpha, x, y, n);
+    return hipGetLastError();
+}
+hipError_t launch_axpy_dev(const float* alpha_dev, float sign, const float* x, float* y, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(axpy_dev_kernel, dim3(vblocks(n)), dim3(256), 0, stream, alpha_dev, sign, x, y, n);
+    return hipGetLastError();
+}
+hipError_t launch_scale_copy(float alpha, const float* x, float* y, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(scale_copy_kernel, dim3(vblocks(n)), dim3(256), 0, stream, alpha, x, y, n);
+    return hipGetLastError();
+}
+hipError_t launch_sub(const float* a, const float* b, float* out, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(sub_kernel, dim3(vblocks(n)), dim3(256), 0, stream, a, b, out, n);
+    return hipGetLastError();
+}
+
+// ---- Adam (single tensor, no amsgrad / weight decay) -----------------------------------------------
+__global__ void adam_kernel(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, float beta1, float beta2, float eps, float step_size,
+                            float bc2_sqrt) {
+    const float w = 1.f - beta1;
+    const float one_m_b2 = 1.f - beta2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float mi = m[i], vi = v[i];
+        mi = mi + w * (gi - mi);                                    // exp_avg.lerp_(grad, 1 - beta1)
+        vi = __fmul_rn(vi, beta2) + one_m_b2 * gi * gi;             // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = __fdiv_rn(__fsqrt_rn(vi), bc2_sqrt) + eps;
+        x[i] = x[i] - step_size * __fdiv_rn(mi, denom);             // addcdiv_(exp_avg, denom, value=-step_size)
+        m[i] = mi;
+        v[i] = vi;
+    }
+}
+hipError_t launch_adam(float* x, const float* g, float* m, float* v, size_t n, float beta1, float beta2, float eps,
+                       float step_size, float bc2_sqrt, hipStream_t stream) {
+    hipLaunchKernelGGL(adam_kernel, dim3(vblocks(n)), dim3(256), 0, stream, x, g, m, v, n, beta1, beta2, eps, step_size,
+                       bc2_sqrt);
+    return hipGetLastError();
+}
+
+}  // namespace nst

@@ -1,0 +1,241 @@
+"""Thin Python handle on the C ABI: device buffers are torch CUDA tensors (plumbing only), every
+computation happens in libnst_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import NST_LOSS_ROW, NstError, StepInfo
+
+TAP_CHANNELS = (64, 128, 256, 512, 512, 512)
+TAP_SCALE = (0, 1, 2, 3, 3, 4)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _chk_dev(t: torch.Tensor, device, shape=None):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise NstError("expected a contiguous float32 CUDA tensor")
+    if t.device != device:
+        raise NstError(f"tensor is on {t.device}, context on {device}")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise NstError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+
+
+class StyleEngine:
+    """One nst_ctx: VGG19 weights on one GPU + the pyramid workspace of one job."""
+
+    def __init__(self, weights: Sequence[Tuple[torch.Tensor, torch.Tensor]], device: int | str | torch.device = 0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise NstError("no GPU visible: the style-transfer hot path runs only on the HIP device")
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if self.device.type != "cuda":
+            raise NstError("StyleEngine needs a cuda (HIP) device; there is no CPU fallback")
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", idx)
+        if len(weights) != _lib.NST_VGG19_CONVS:
+            raise NstError("expected 13 (weight, bias) pairs conv1_1..conv5_1")
+        ws = [np.ascontiguousarray(w.detach().cpu().numpy(), dtype=np.float32) for w, _ in weights]
+        bs = [np.ascontiguousarray(b.detach().cpu().numpy(), dtype=np.float32) for _, b in weights]
+        wp = (C.c_void_p * 13)(*[a.ctypes.data for a in ws])
+        bp = (C.c_void_p * 13)(*[a.ctypes.data for a in bs])
+        ctx = C.c_void_p()
+        _lib.check(None, self.lib.nst_ctx_create(idx, wp, bp, C.byref(ctx)), "nst_ctx_create")
+        self.ctx = ctx
+        self.levels = 0
+        self.shape = None
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.nst_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- job ------------------------------------------------------------------------------------
+    def configure(self, levels_num: int, H0: int, W0: int) -> None:
+        _lib.check(self.ctx, self.lib.nst_job_configure(self.ctx, levels_num, H0, W0), "nst_job_configure")
+        self.levels = levels_num
+        self.shape = (H0, W0)
+
+    def level_shape(self, level: int) -> Tuple[int, int]:
+        h, w = self.shape
+        return h >> level, w >> level
+
+    def set_targets(self, level: int, content: torch.Tensor, style: torch.Tensor) -> None:
+        h, w = self.level_shape(level)
+        content = content.reshape(3, h, w)
+        _chk_dev(content, self.device)
+        style = style.reshape(3, style.shape[-2], style.shape[-1])
+        _chk_dev(style, self.device)
+        _lib.check(self.ctx, self.lib.nst_level_set_targets(self.ctx, level, _ptr(content), _ptr(style),
+                                                            style.shape[1], style.shape[2], _stream(self.device)),
+                   "nst_level_set_targets")
+
+    def closure(self, x: torch.Tensor, cw: float, sw: float, tvw: float,
+                grad: Optional[torch.Tensor] = None, losses: Optional[torch.Tensor] = None):
+        """Asynchronous on the current stream. Returns (grad (3,H,W), losses (4*levels+1,)) device tensors."""
+        H, W = self.shape
+        _chk_dev(x, self.device)
+        if x.numel() != 3 * H * W:
+            raise NstError("x has the wrong number of elements")
+        if grad is None:
+            grad = torch.empty((1, 3, H, W), dtype=torch.float32, device=self.device)
+        if losses is None:
+            losses = torch.empty(NST_LOSS_ROW * self.levels + 1, dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_closure(self.ctx, _ptr(x), cw, sw, tvw, _ptr(grad), _ptr(losses),
+                                                  _stream(self.device)), "nst_closure")
+        return grad, losses
+
+    def bytes(self) -> int:
+        n = C.c_size_t()
+        _lib.check(self.ctx, self.lib.nst_ctx_bytes(self.ctx, C.byref(n)), "nst_ctx_bytes")
+        return n.value
+
+    # ---- timing ---------------------------------------------------------------------------------
+    def set_timing(self, mode: int) -> None:
+        _lib.check(self.ctx, self.lib.nst_set_timing(self.ctx, mode), "nst_set_timing")
+
+    def last_closure_ms(self) -> float:
+        ms = C.c_float()
+        _lib.check(self.ctx, self.lib.nst_last_closure_ms(self.ctx, C.byref(ms)), "nst_last_closure_ms")
+        return ms.value
+
+    def last_closure_class(self, cls: int):
+        ms, n, fl = C.c_float(), C.c_int(), C.c_double()
+        _lib.check(self.ctx, self.lib.nst_last_closure_class(self.ctx, cls, C.byref(ms), C.byref(n), C.byref(fl)),
+                   "nst_last_closure_class")
+        return ms.value, n.value, fl.value
+
+    # ---- standalone pieces (unit parity) ----------------------------------------------------------
+    def vgg_features(self, x: torch.Tensor) -> List[torch.Tensor]:
+        x = x.reshape(3, x.shape[-2], x.shape[-1])
+        _chk_dev(x, self.device)
+        h, w = x.shape[1], x.shape[2]
+        outs = [torch.empty((1, c, h >> s, w >> s), dtype=torch.float32, device=self.device)
+                for c, s in zip(TAP_CHANNELS, TAP_SCALE)]
+        arr = (C.c_void_p * 6)(*[o.data_ptr() for o in outs])
+        _lib.check(self.ctx, self.lib.nst_vgg_features(self.ctx, _ptr(x), h, w, arr, _stream(self.device)),
+                   "nst_vgg_features")
+        return outs
+
+    def vgg_features_backward(self, x: torch.Tensor, gouts: Sequence[Optional[torch.Tensor]]) -> torch.Tensor:
+        x = x.reshape(3, x.shape[-2], x.shape[-1])
+        _chk_dev(x, self.device)
+        h, w = x.shape[1], x.shape[2]
+        for g in gouts:
+            if g is not None:
+                _chk_dev(g, self.device)
+        arr = (C.c_void_p * 6)(*[(g.data_ptr() if g is not None else 0) for g in gouts])
+        gx = torch.empty((1, 3, h, w), dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_vgg_features_backward(self.ctx, _ptr(x), h, w, arr, _ptr(gx),
+                                                                _stream(self.device)), "nst_vgg_features_backward")
+        return gx
+
+    def gram(self, f: torch.Tensor, normalize: bool = True) -> torch.Tensor:
+        _chk_dev(f, self.device)
+        b, c, h, w = f.shape
+        assert b == 1
+        g = torch.empty((1, c, c), dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_gram(self.ctx, _ptr(f), c, h, w, int(normalize), _ptr(g),
+                                               _stream(self.device)), "nst_gram")
+        return g
+
+    def total_variation(self, y: torch.Tensor, want_grad: bool = False):
+        _chk_dev(y, self.device)
+        b, c, h, w = y.shape
+        val = torch.empty(1, dtype=torch.float32, device=self.device)
+        grad = torch.empty_like(y) if want_grad else None
+        _lib.check(self.ctx, self.lib.nst_total_variation(self.ctx, _ptr(y), b * c, h, w, _ptr(val), _ptr(grad),
+                                                          _stream(self.device)), "nst_total_variation")
+        return (val, grad) if want_grad else val
+
+    def bicubic_half(self, x: torch.Tensor) -> torch.Tensor:
+        _chk_dev(x, self.device)
+        b, c, h, w = x.shape
+        y = torch.empty((b, c, h // 2, w // 2), dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_bicubic_half(self.ctx, _ptr(x), b * c, h, w, _ptr(y), _stream(self.device)),
+                   "nst_bicubic_half")
+        return y
+
+    def bicubic_half_backward(self, gy: torch.Tensor, h: int, w: int) -> torch.Tensor:
+        _chk_dev(gy, self.device)
+        b, c = gy.shape[0], gy.shape[1]
+        gx = torch.empty((b, c, h, w), dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_bicubic_half_backward(self.ctx, _ptr(gy), b * c, h, w, _ptr(gx),
+                                                                _stream(self.device)), "nst_bicubic_half_backward")
+        return gx
+
+    def prepare_img(self, hwc: torch.Tensor) -> torch.Tensor:
+        _chk_dev(hwc, self.device)
+        h, w, _ = hwc.shape
+        out = torch.empty((1, 3, h, w), dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_prepare_img(self.ctx, _ptr(hwc), h, w, _ptr(out), _stream(self.device)),
+                   "nst_prepare_img")
+        return out
+
+    def unprepare_img(self, chw: torch.Tensor) -> torch.Tensor:
+        _chk_dev(chw, self.device)
+        h, w = chw.shape[-2], chw.shape[-1]
+        out = torch.empty((h, w, 3), dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_unprepare_img(self.ctx, _ptr(chw), h, w, _ptr(out), _stream(self.device)),
+                   "nst_unprepare_img")
+        return out
+
+
+class PixelOptimizer:
+    """nst_opt: torch.optim.Adam / LBFGS as the reference constructs them, driving the closure."""
+
+    def __init__(self, engine: StyleEngine, name: str, lr_start: float = 10.0, lbfgs_max_eval: int = 1):
+        if name == "adam":
+            kind = _lib.NST_OPT_ADAM
+        elif name == "lbfgs":
+            kind = _lib.NST_OPT_LBFGS
+        else:
+            raise RuntimeError("Unknown optimizer")   # neural_style_transfer.py:137-138
+        self.engine = engine
+        self.name = name
+        h = C.c_void_p()
+        _lib.check(engine.ctx, engine.lib.nst_opt_create(engine.ctx, kind, lr_start, lbfgs_max_eval, C.byref(h)),
+                   "nst_opt_create")
+        self.h = h
+        self.row = NST_LOSS_ROW * engine.levels + 1
+        self.cap = 32 if name == "lbfgs" else 1
+        self._rows = np.zeros((self.cap, self.row), dtype=np.float32)
+
+    def step(self, x: torch.Tensor, cw: float, sw: float, tvw: float, want_losses: bool = True):
+        """One optimizer.step(closure). Returns (StepInfo, rows[closures, 4*levels+1] or None)."""
+        e = self.engine
+        _chk_dev(x, e.device)
+        info = StepInfo()
+        ptr = C.c_void_p(self._rows.ctypes.data) if want_losses else C.c_void_p(0)
+        _lib.check(e.ctx, e.lib.nst_opt_step(self.h, _ptr(x), cw, sw, tvw, ptr, self.cap, C.byref(info),
+                                             _stream(e.device)), "nst_opt_step")
+        rows = self._rows[:min(info.closures, self.cap)].copy() if want_losses else None
+        return info, rows
+
+    def close(self):
+        if getattr(self, "h", None) and getattr(self.engine, "ctx", None):
+            self.engine.lib.nst_opt_destroy(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

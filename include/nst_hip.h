@@ -1,0 +1,137 @@
+/*
+ * nst_hip.h - C ABI of libnst_hip.so, the MI355X (gfx950) implementation of the pyramid
+ * neural-style-transfer hot path.
+ *
+ * The reference (irenemizus/ArtStyleTransfer) has no FFI of its own: its hot path is Python on top
+ * of torch ops.  Each entry point below names the reference interface it replaces
+ * (file:line in the reference checkout; "torch:" = the torch package the reference calls into).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative NST_E_* code on failure, never throws;
+ *     nst_last_error(ctx) returns a description of the last failure on that context
+ *     (nst_last_error(NULL): the last failure of a call that had no context, thread-local).
+ *   - the caller owns every image / gradient / optimiser buffer and passes raw DEVICE pointers
+ *     plus the hipStream_t (as void*) the work must be ordered on; the context owns the VGG
+ *     weights (pre-transformed), the per-level targets and the activation workspace.
+ *   - images on the device are fp32 planar (3, H, W) in the reference's "prepared" domain
+ *     (RGB * 255 - ImageNet mean: neural_style_transfer.py:375-383), exactly the storage of the
+ *     (1,3,H,W) torch tensor the reference optimises.
+ *   - every entry point binds the context's device itself (callers hop between thread-pool
+ *     threads: neural_style_transfer.py:206) and is re-entrant across contexts.
+ */
+#ifndef NST_HIP_H
+#define NST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NST_OK 0
+#define NST_E_ARG (-1)      /* bad argument (null pointer, bad size, unknown enum) */
+#define NST_E_STATE (-2)    /* call order violated (e.g. closure before targets) */
+#define NST_E_HIP (-3)      /* a HIP runtime call failed; see nst_last_error */
+#define NST_E_NOMEM (-4)
+
+#define NST_VGG19_CONVS 13  /* conv1_1 ... conv5_1 (torchvision features[0:30]) */
+#define NST_MAX_LEVELS 8
+#define NST_LOSS_ROW 4      /* per level: total, content, style, tv */
+
+typedef struct nst_ctx nst_ctx;
+typedef struct nst_opt nst_opt;
+
+/* library / device ------------------------------------------------------------------------ */
+int nst_version(void);
+const char* nst_last_error(const nst_ctx* ctx);
+/* number of visible HIP devices (does not initialise a context on any of them) */
+int nst_device_count(int* count);
+
+/* context: VGG19 feature network of math_utils.prepare_model (math_utils.py:9-23) and
+ * neural_nets.Vgg19.__init__ (neural_nets.py:17-51).  weights[i]: HOST pointer, (Cout,Cin,3,3)
+ * fp32 in torchvision order conv1_1..conv5_1; biases[i]: HOST pointer (Cout).  The context
+ * keeps device copies re-laid-out for the forward and the input-gradient kernels. */
+int nst_ctx_create(int device, const float* const* weights, const float* const* biases, nst_ctx** out);
+void nst_ctx_destroy(nst_ctx* ctx);
+
+/* pyramid geometry of one job: levels_num levels, level 0 = (H0, W0), level l = previous // 2
+ * (neural_style_transfer.py:170-176).  Allocates the activation workspace of every level. */
+int nst_job_configure(nst_ctx* ctx, int levels_num, int H0, int W0);
+
+/* LossBuilder.__init__ (neural_style_transfer.py:68-82): target content representation
+ * ReLU(conv4_2) of the content image and the 5 target Gram matrices of the style image of one
+ * level.  content: device (3,h,w) of that level's size; style: device (3,hs,ws), any size. */
+int nst_level_set_targets(nst_ctx* ctx, int level, const float* content, const float* style,
+                          int hs, int ws, void* stream);
+
+/* optimizer_step_callback without its LR decay and prints (neural_style_transfer.py:152-199) =
+ * sum over levels of LossBuilder.build (:84-112) on the bicubic 1/2 chain of x (:170-176),
+ * then backward (:193).  x, grad: device (3,H0,W0).  losses: device, NST_LOSS_ROW*levels+1
+ * floats = per level (total, content, style, tv) unweighted components as the reference
+ * prints them, then the grand total.  Asynchronous on `stream`. */
+int nst_closure(nst_ctx* ctx, const float* x, float content_weight, float style_weight,
+                float tv_weight, float* grad, float* losses, void* stream);
+
+/* torch.optim.Adam / torch.optim.LBFGS as constructed at neural_style_transfer.py:134-136,
+ * driving nst_closure, including the closure's `lr *= 0.999` (:155-158).  kind: 0 = adam
+ * (torch:optim/adam.py:457-546, betas (0.9,0.999), eps 1e-8), 1 = lbfgs
+ * (torch:optim/lbfgs.py:332-537: max_iter 1, strong_wolfe, history 100; lbfgs_max_eval is the
+ * constructor's max_eval: 1 = torch 2.10 behaviour of the reference's arguments, 26 = legacy
+ * line search). */
+#define NST_OPT_ADAM 0
+#define NST_OPT_LBFGS 1
+int nst_opt_create(nst_ctx* ctx, int kind, float lr_start, int lbfgs_max_eval, nst_opt** out);
+void nst_opt_destroy(nst_opt* opt);
+
+typedef struct nst_step_info {
+    int closures;        /* closure evaluations made by this step (Adam 1, L-BFGS >= 1) */
+    int total_closures;  /* the reference's `step` counter after this call */
+    int accepted;        /* L-BFGS: 1 if x moved, 0 if the trial was rejected; Adam: 1 */
+    float loss;          /* loss of the FIRST closure of this step (what optimizer.step returns) */
+    float lr;            /* learning rate after this step's decays */
+    float t;             /* L-BFGS step length taken (0 when rejected) */
+} nst_step_info;
+
+/* one optimizer.step(closure) (neural_style_transfer.py:205-206).  x: device (3,H0,W0), updated
+ * in place.  losses_host (nullable): HOST buffer of closures_capacity*(NST_LOSS_ROW*levels+1)
+ * floats receiving the loss rows of every closure made.  Synchronous for L-BFGS (host control
+ * flow needs the loss), asynchronous on `stream` for Adam when losses_host is NULL. */
+int nst_opt_step(nst_opt* opt, float* x, float content_weight, float style_weight, float tv_weight,
+                 float* losses_host, int closures_capacity, nst_step_info* info, void* stream);
+
+/* ---- standalone pieces of the path, exported for unit parity -------------------------------- */
+
+/* Vgg19.forward (neural_nets.py:53-68): x device (3,h,w) -> the six maps, each written as
+ * (C,h_i,w_i) planar fp32 (reference layout) into outs[i] (device; NULL to skip). */
+int nst_vgg_features(nst_ctx* ctx, const float* x, int h, int w, float* const* outs, void* stream);
+/* d(sum_i <outs_i, gouts_i>)/dx through the network: gouts[i] device (C,h_i,w_i) or NULL. */
+int nst_vgg_features_backward(nst_ctx* ctx, const float* x, int h, int w, const float* const* gouts,
+                              float* gx, void* stream);
+/* math_utils.gram_matrix (math_utils.py:26-34): f device (C,h,w) -> gram device (C,C). */
+int nst_gram(nst_ctx* ctx, const float* f, int C, int h, int w, int normalize, float* gram, void* stream);
+/* math_utils.total_variation (math_utils.py:37-41): value (device scalar) and, if grad != NULL,
+ * grad (C,h,w) = d tv / d y. */
+int nst_total_variation(nst_ctx* ctx, const float* y, int C, int h, int w, float* value, float* grad,
+                        void* stream);
+/* F.interpolate(x, size=(h//2,w//2), mode='bicubic') (neural_style_transfer.py:173-176) and its
+ * transpose (autograd backward); x (C,h,w) -> y (C,h/2,w/2); gy -> gx (overwritten). */
+int nst_bicubic_half(nst_ctx* ctx, const float* x, int C, int h, int w, float* y, void* stream);
+int nst_bicubic_half_backward(nst_ctx* ctx, const float* gy, int C, int h, int w, float* gx, void* stream);
+/* prepare_img / unprepare_img (neural_style_transfer.py:375-393): HWC [0,1] RGB <-> planar
+ * prepared, both on the device. */
+int nst_prepare_img(nst_ctx* ctx, const float* hwc, int h, int w, float* chw, void* stream);
+int nst_unprepare_img(nst_ctx* ctx, const float* chw, int h, int w, float* hwc, void* stream);
+
+/* workspace bytes currently held by the context (activations, gradients, history, targets) */
+int nst_ctx_bytes(const nst_ctx* ctx, size_t* bytes);
+
+/* wall time in ms of the kernels of the last nst_closure on `ctx`, measured with HIP events on
+ * the streams the kernels ran on (0 if timing was not enabled with nst_set_timing). */
+int nst_set_timing(nst_ctx* ctx, int enabled);
+int nst_last_closure_ms(nst_ctx* ctx, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NST_HIP_H */
