@@ -399,22 +399,26 @@ hipError_t launch_mse_grad(const float* a, const float* t, size_t n, float coef,
 __constant__ float kMean[3] = {123.675f, 116.28f, 103.53f};
 __constant__ double kMeanD[3] = {123.675, 116.28, 103.53};
 
+// hipcc contracts a*b+c into one fma by default; these three kernels restate host arithmetic that
+// rounds after every operation, so contraction is switched off inside them.
 __global__ void prepare_img_kernel(const float* __restrict__ hwc, size_t HW, float* __restrict__ chw) {
+#pragma clang fp contract(off)
     const size_t total = HW * 3;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t p = i % HW;
         const int c = (int)(i / HW);
-        chw[i] = __fsub_rn(__fmul_rn(hwc[p * 3 + c], 255.f), kMean[c]);
+        chw[i] = hwc[p * 3 + c] * 255.f - kMean[c];     // two roundings (x.mul(255) then Normalize)
     }
 }
 __global__ void unprepare_img_kernel(const float* __restrict__ chw, size_t HW, float* __restrict__ hwc) {
+#pragma clang fp contract(off)
     const size_t total = HW * 3;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % 3);
         const size_t p = i / 3;
         // numpy: float32 += float64 array (computed in double, rounded to float32), then / 255 in float32
         const float v = (float)((double)chw[(size_t)c * HW + p] + kMeanD[c]);
-        hwc[i] = __fdiv_rn(v, 255.f);
+        hwc[i] = v / 255.f;
     }
 }
 hipError_t launch_prepare_img(const float* hwc, int h, int w, float* chw, hipStream_t stream) {
@@ -430,6 +434,7 @@ hipError_t launch_unprepare_img(const float* chw, int h, int w, float* hwc, hipS
 
 // ------------------------------------------------------------------ loss rows (neural_style_transfer.py:95-110, :179-185)
 __global__ __launch_bounds__(256) void loss_assemble_kernel(LossAssembly la) {
+#pragma clang fp contract(off)
     __shared__ double sh[4];
     __shared__ float tot;
     for (int l = 0; l < la.levels; ++l) {
@@ -441,18 +446,18 @@ __global__ __launch_bounds__(256) void loss_assemble_kernel(LossAssembly la) {
         if (threadIdx.x == 0) {
             const float content = (float)(cs / (double)in.content_n);
             float style = 0.f;
-            for (int k = 0; k < 5; ++k)
-                style = __fadd_rn(style, (float)(ss[k] / ((double)in.style_c[k] * in.style_c[k])));
-            style = __fdiv_rn(style, 5.f);
+            for (int k = 0; k < 5; ++k) style = style + (float)(ss[k] / ((double)in.style_c[k] * in.style_c[k]));
+            style = style / 5.f;
             const float mx = in.tv_means[0], my = in.tv_means[1];
-            const float tv = __fadd_rn(__fmul_rn(mx, mx), __fmul_rn(my, my));
-            const float total = __fadd_rn(__fadd_rn(__fmul_rn(la.cw, content), __fmul_rn(la.sw, style)),
-                                          __fmul_rn(la.tvw, tv));
+            const float tv = mx * mx + my * my;
+            // cw*content + sw*style + tvw*tv, each product and sum rounded (contraction is off here)
+            const float t0 = la.cw * content, t1 = la.sw * style, t2 = la.tvw * tv;
+            const float total = (t0 + t1) + t2;
             la.out[4 * l + 0] = total;
             la.out[4 * l + 1] = content;
             la.out[4 * l + 2] = style;
             la.out[4 * l + 3] = tv;
-            tot = (l == 0) ? total : __fadd_rn(__fmul_rn(1.0f, tot), total);
+            tot = (l == 0) ? total : (1.0f * tot + total);
         }
         __syncthreads();
     }

@@ -79,9 +79,9 @@ class StyleEngine:
 
     def set_targets(self, level: int, content: torch.Tensor, style: torch.Tensor) -> None:
         h, w = self.level_shape(level)
-        content = content.reshape(3, h, w)
+        content = content.contiguous().reshape(3, h, w)
         _chk_dev(content, self.device)
-        style = style.reshape(3, style.shape[-2], style.shape[-1])
+        style = style.contiguous().reshape(3, style.shape[-2], style.shape[-1])
         _chk_dev(style, self.device)
         _lib.check(self.ctx, self.lib.nst_level_set_targets(self.ctx, level, _ptr(content), _ptr(style),
                                                             style.shape[1], style.shape[2], _stream(self.device)),

@@ -1,0 +1,98 @@
+"""Feature network surface of the reference (neural_nets.py:10-68) on top of the HIP engine.
+
+`Vgg19` keeps the reference's attributes (`layer_names`, `content_feature_maps_index`,
+`style_feature_maps_indices`) and returns the same `VggOutputs` namedtuple, but holds no
+torch modules: the 13 frozen conv layers live, re-laid-out, inside a `StyleEngine` per GPU.
+Pretrained weights cannot be downloaded offline (neural_nets.py:19 fetches them): point
+NST_VGG19_WEIGHTS at a local torchvision `vgg19` state-dict file, otherwise seeded synthetic
+weights are used and a warning is printed."""
+from __future__ import annotations
+
+import os
+import threading
+import warnings
+from collections import namedtuple
+from typing import Dict, List, Tuple
+
+import torch
+
+from . import synthetic
+from .engine import StyleEngine
+
+_FEATURE_CONV_INDICES = (0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 23, 25, 28)   # torchvision vgg19.features
+_weights_cache = None
+_engines: Dict[int, StyleEngine] = {}
+_lock = threading.Lock()
+
+
+def load_weights() -> List[Tuple[torch.Tensor, torch.Tensor]]:
+    global _weights_cache
+    if _weights_cache is not None:
+        return _weights_cache
+    path = os.environ.get("NST_VGG19_WEIGHTS")
+    if path:
+        sd = torch.load(path, map_location="cpu")
+        ws = [(sd[f"features.{i}.weight"].float(), sd[f"features.{i}.bias"].float()) for i in _FEATURE_CONV_INDICES]
+    else:
+        warnings.warn("NST_VGG19_WEIGHTS is not set: using seeded synthetic VGG19 weights "
+                      "(results are not artistically meaningful)")
+        ws = synthetic.vgg19_weights()
+    _weights_cache = ws
+    return ws
+
+
+def set_weights(weights) -> None:
+    """Install (weight, bias) pairs conv1_1..conv5_1; drops engines built on the old ones."""
+    global _weights_cache
+    with _lock:
+        _weights_cache = list(weights)
+        for e in _engines.values():
+            e.close()
+        _engines.clear()
+
+
+def shared_engine(device) -> StyleEngine:
+    """The per-GPU engine used by the stand-alone helpers (gram_matrix, Vgg19.forward, ...)."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _lock:
+        if idx not in _engines:
+            _engines[idx] = StyleEngine(load_weights(), idx)
+        return _engines[idx]
+
+
+class Vgg19:
+    """Only the layers the original NST paper uses are exposed (relu1_1, relu2_1, relu3_1, relu4_1,
+    conv4_2, relu5_1); 'conv4_2' carries ReLU(conv4_2) exactly as the reference's in-place ReLU
+    leaves it."""
+
+    def __init__(self, requires_grad=False, show_progress=False, use_relu=True):
+        if requires_grad:
+            raise NotImplementedError("the feature network is frozen; only the image is optimised")
+        if not use_relu:
+            raise NotImplementedError("use_relu=False (pre-activation taps) is not on the reference's path")
+        self.layer_names = ["relu1_1", "relu2_1", "relu3_1", "relu4_1", "conv4_2", "relu5_1"]
+        self.offset = 1
+        self.content_feature_maps_index = 4
+        self.style_feature_maps_indices = [0, 1, 2, 3, 5]
+        self.weights = load_weights()
+        self.device = None
+
+    def to(self, device):
+        self.device = torch.device(device)
+        return self
+
+    def eval(self):
+        return self
+
+    def parameters(self):
+        for w, b in self.weights:
+            yield w
+            yield b
+
+    def forward(self, x: torch.Tensor):
+        eng = shared_engine(x.device)
+        outs = eng.vgg_features(x.contiguous())
+        return namedtuple("VggOutputs", self.layer_names)(*outs)
+
+    __call__ = forward

@@ -1,0 +1,184 @@
+"""Job driver and optimisation loop with the reference's public surface
+(neural_style_transfer.py:32-439), re-implemented on the MI355X HIP engine.
+
+What changed underneath: the reference builds an autograd graph per closure out of torch ops and
+lets torch.optim walk it; here one `nst_opt_step` call runs the whole `optimizer.step(closure)` -
+pyramid down-sampling, VGG19 forward of every level, Gram/content/TV losses, the hand-written
+backward and the Adam / L-BFGS update - inside libnst_hip.so on the device-resident pixel buffer.
+There is no CPU path: without a GPU and the built extension these entry points raise."""
+from __future__ import annotations
+
+import asyncio
+import traceback
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import host_image, math_utils
+from .engine import PixelOptimizer, StyleEngine
+from .neural_nets import load_weights, shared_engine
+
+# ImageNet statistics (reference :22-23)
+IMAGENET_MEAN_255 = [123.675, 116.28, 103.53]
+IMAGENET_STD_NEUTRAL = [1, 1, 1]
+
+# how many closure evaluations LBFGS may spend per step; 1 = torch 2.10 semantics of the reference's
+# constructor arguments, 26 = the line search older torch builds performed
+LBFGS_MAX_EVAL = 1
+VERBOSE = False
+
+
+class ContentStylePair:
+    """content = (name, HWC float32 RGB [0,1] image), style = (name, image)."""
+
+    def __init__(self, content, style):
+        self.content = content
+        self.style = style
+
+
+def prepare_img(img, device):
+    """HWC [0,1] -> (1,3,H,W) `*255 - ImageNet mean` on `device` (reference :375-383)."""
+    dev = torch.device(device)
+    hwc = torch.from_numpy(np.ascontiguousarray(img, dtype=np.float32)).to(dev)
+    return shared_engine(dev).prepare_img(hwc)
+
+
+def unprepare_img(img: torch.Tensor):
+    """(1,3,H,W) -> HWC float32 numpy, `(+mean)/255`, not clipped (reference :386-393)."""
+    t = img.detach().contiguous()
+    return shared_engine(t.device).unprepare_img(t).cpu().numpy()
+
+
+class RepresentationBuilder:
+    """Content / style representations of an image from the network's six feature maps."""
+
+    def __init__(self, image, neural_net):
+        self.__features = neural_net(image)
+
+    def build_content(self, feature_map_indices):
+        listed = isinstance(feature_map_indices, list)
+        idx = feature_map_indices if listed else [feature_map_indices]
+        rep = [x.squeeze(0) for i, x in enumerate(self.__features) if i in idx]
+        return rep if listed else rep[0]
+
+    def build_style(self, feature_map_indices):
+        listed = isinstance(feature_map_indices, list)
+        idx = feature_map_indices if listed else [feature_map_indices]
+        rep = [math_utils.gram_matrix(x) for i, x in enumerate(self.__features) if i in idx]
+        return rep if listed else rep[0]
+
+
+class LossBuilder:
+    """Loss of one pyramid level. `build(x)` returns (total, content, style, tv) as device scalars
+    evaluated by the fused HIP closure (they carry no autograd graph; the loop obtains the
+    gradient from the same closure call)."""
+
+    def __init__(self, content_feature_maps_index, style_feature_maps_indices, target_content_image,
+                 target_style_image, neural_net, content_weight, style_weight, tv_weight):
+        if content_feature_maps_index != 4 or list(style_feature_maps_indices) != [0, 1, 2, 3, 5]:
+            raise ValueError("the HIP closure implements the reference's VGG19 taps (content 4, style [0,1,2,3,5])")
+        self.__weights = (float(content_weight), float(style_weight), float(tv_weight))
+        c = target_content_image
+        self.__engine = StyleEngine(load_weights(), c.device)
+        self.__engine.configure(1, c.shape[-2], c.shape[-1])
+        self.__engine.set_targets(0, c.contiguous(), target_style_image.contiguous())
+
+    def build(self, optimizing_img):
+        cw, sw, tvw = self.__weights
+        _, losses = self.__engine.closure(optimizing_img.detach().contiguous(), cw, sw, tvw)
+        return losses[0], losses[1], losses[2], losses[3]
+
+
+class NeuralStyleTransfer:
+    """The optimisation loop (reference :115-208)."""
+
+    def __init__(self, device, model_name, style_imgs, optimizer_name):
+        self.__device = torch.device(device)
+        self.__model_name = model_name
+        self.__style_imgs = style_imgs
+        self.__optimizer_name = optimizer_name
+
+    async def process(self, content_imgs, init_img, lr_start, iters_num, content_weight, style_weight, tv_weight,
+                      init_img_name):
+        # validates the model name exactly as the reference does (ValueError for anything but vgg19)
+        math_utils.prepare_model(self.__model_name, self.__device)
+        if self.__optimizer_name not in ("adam", "lbfgs"):
+            raise RuntimeError("Unknown optimizer")
+        if self.__device.type != "cuda":
+            raise RuntimeError("the HIP style-transfer engine needs a GPU; no CPU path exists")
+        dev = self.__device
+        h0, w0 = init_img.shape[:2]
+        engine = StyleEngine(load_weights(), dev)
+        try:
+            engine.configure(len(content_imgs), h0, w0)
+            for lvl, (c_img, s_img) in enumerate(zip(content_imgs, self.__style_imgs)):
+                if tuple(c_img.shape[:2]) != engine.level_shape(lvl):
+                    raise ValueError(f"content level {lvl} is {c_img.shape[:2]}, expected {engine.level_shape(lvl)}")
+                engine.set_targets(lvl, prepare_img(c_img, dev), prepare_img(s_img, dev))
+            optimizing_img = prepare_img(init_img, dev)
+            optimizer = PixelOptimizer(engine, self.__optimizer_name, lr_start, LBFGS_MAX_EVAL)
+            cw, sw, tvw = float(content_weight), float(style_weight), float(tv_weight)
+            step = 0
+
+            def one_step():
+                try:
+                    return optimizer.step(optimizing_img, cw, sw, tvw, want_losses=True)
+                except Exception:
+                    traceback.print_exc()
+                    raise
+
+            loop = asyncio.get_running_loop()
+            while step < iters_num:
+                info, rows = await loop.run_in_executor(None, one_step)
+                step = info.total_closures
+                if VERBOSE:
+                    for r in rows:
+                        print(f"{self.__optimizer_name} | {init_img_name} | lr={info.lr:.4f} | total loss={r[-1]:.3e}")
+                yield unprepare_img(optimizing_img), step
+            optimizer.close()
+        finally:
+            engine.close()
+
+
+async def resize(img, level):
+    """Image resized for pyramid level `level`: short edge 256 * 2**level, bicubic, always from the
+    original (reference :211-226)."""
+    return host_image.resize_to_level(np.array(img, copy=True), level)
+
+
+gaussian_mask = host_image.gaussian_mask
+make_style_noise = host_image.make_style_noise
+
+
+async def neural_style_transfer(content_n_style: ContentStylePair,
+                                content_weight, style_weight, tv_weight,
+                                optimizer, model, init_method,
+                                iters_num, levels_num, noise_factor, noise_levels, noise_levels_central_amplitude,
+                                noise_levels_peripheral_amplitude, noise_levels_dispersion, device=None):
+    """Async generator yielding (percent, HWC float32 image) after every optimiser step
+    (reference :229-372). `device` (extension): the GPU to run on; default = current."""
+    if device is None:
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the HIP style-transfer engine has no CPU path")
+        device = torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+
+    content_levels: List[np.ndarray] = []
+    style_levels: List[np.ndarray] = []
+    level = 0
+    for level in range(levels_num):
+        content_levels.insert(0, await resize(content_n_style.content[1], level=level))
+        style_levels.insert(0, await resize(content_n_style.style[1], level=level))
+
+    init_img, tag = host_image.initial_image(
+        init_method, content_n_style.content[1], content_n_style.style[1], content_levels[0], style_levels[0], level,
+        noise_factor, noise_levels, noise_levels_central_amplitude, noise_levels_peripheral_amplitude,
+        noise_levels_dispersion)
+    init_name = {"random": "random", "content": content_n_style.content[0], "style": content_n_style.style[0]}[tag]
+
+    nst = NeuralStyleTransfer(device, model, style_levels, optimizer)
+    lr_start = 10.0
+    async for img, cur_iter in nst.process(content_levels, init_img, lr_start, iters_num, content_weight,
+                                           style_weight, tv_weight, init_name):
+        yield cur_iter / iters_num * 100.0, img
