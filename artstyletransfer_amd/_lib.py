@@ -56,6 +56,9 @@ SYMBOLS = {
     "nst_last_closure_ms": (C.c_int, [c_void, C.POINTER(C.c_float)]),
     "nst_last_closure_class": (C.c_int, [c_void, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int),
                                          C.POINTER(C.c_double)]),
+    "nst_dump_last_closure": (C.c_int, [c_void]),
+    "nst_timing_totals": (C.c_int, [c_void, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long),
+                                    C.POINTER(C.c_double), C.c_int]),
 }
 
 _lib = None

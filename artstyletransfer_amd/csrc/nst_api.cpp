@@ -40,7 +40,7 @@ struct ActSet {                 // activations of one forward pass, NHWC
 
 enum KClass { K_CONV3 = 0, K_GRAM = 1, K_CONV1 = 2, K_OTHER = 3, K_NCLASS = 4 };
 
-struct TimedLaunch { hipEvent_t a, b; int cls; double flops; };
+struct TimedLaunch { hipEvent_t a, b; int cls; double flops; int tag[6]; };
 
 struct LevelWs {
     int h = 0, w = 0;
@@ -86,6 +86,12 @@ struct nst_ctx {
     size_t ev_used = 0;
     std::vector<TimedLaunch> timed;
     bool timed_valid = false;
+    // accumulated over closures since the last reset (timing mode 2)
+    double acc_ms[4] = {0, 0, 0, 0};
+    double acc_flops[4] = {0, 0, 0, 0};
+    long acc_launches[4] = {0, 0, 0, 0};
+    double acc_closure_ms = 0;
+    long acc_closures = 0;
 };
 
 namespace {
@@ -153,10 +159,12 @@ int pool_index_after(int l) {
 // ---- timed launches ---------------------------------------------------------------------------
 struct Timer {
     nst_ctx* ctx; hipStream_t s; bool on; size_t slot;
-    Timer(nst_ctx* c, hipStream_t st, int cls, double flops) : ctx(c), s(st), on(false), slot(0) {
+    Timer(nst_ctx* c, hipStream_t st, int cls, double flops, int t0 = 0, int t1 = 0, int t2 = 0, int t3 = 0, int t4 = 0,
+          int t5 = 0)
+        : ctx(c), s(st), on(false), slot(0) {
         if (c->timing >= 2 && c->ev_used + 2 <= c->ev_pool.size()) {
             on = true;
-            TimedLaunch t{c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1], cls, flops};
+            TimedLaunch t{c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1], cls, flops, {t0, t1, t2, t3, t4, t5}};
             c->ev_used += 2;
             slot = c->timed.size();
             c->timed.push_back(t);
@@ -181,7 +189,7 @@ int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s
         p.in = in; p.wt = ctx->wf[l]; p.bias = ctx->bias[l]; p.addend = nullptr; p.mask = nullptr; p.out = a.act[l];
         p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCin[l]; p.Cout = kCout[l]; p.relu = 1;
         {
-            Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9));
+            Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, l);
             HIPCHK(ctx, launch_conv_mfma(p, 9, s));
         }
         const int pa = pool_index_after(l);
@@ -234,7 +242,7 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
         p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCout[l]; p.Cout = kCin[l];
         if (pk >= 0) {
             {
-                Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9));
+                Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, -l);
                 HIPCHK(ctx, launch_conv_mfma(p, 9, s));
             }
             // oth = g(pool[pk]); un-pool through act[l-1] with its ReLU mask -> cur
@@ -260,7 +268,7 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
             }
             p.mask = a.act[m];
             {
-                Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9));
+                Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, -l);
                 HIPCHK(ctx, launch_conv_mfma(p, 9, s));
             }
             float* tmp = cur; cur = oth; oth = tmp;
@@ -304,6 +312,28 @@ void free_level(nst_ctx* ctx, LevelWs& L) {
     if (L.stream) (void)hipStreamDestroy(L.stream);
     if (L.done) (void)hipEventDestroy(L.done);
     L = LevelWs();
+}
+
+// folds the event pairs of the previous closure into the accumulators (waits for them to complete)
+int fold_timed(nst_ctx* ctx) {
+    if (!ctx->timed_valid) return NST_OK;
+    HIPCHK(ctx, hipEventSynchronize(ctx->t1));
+    float ms = 0.f;
+    HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
+    ctx->acc_closure_ms += ms;
+    ctx->acc_closures += 1;
+    for (const TimedLaunch& t : ctx->timed) {
+        float d = 0.f;
+        HIPCHK(ctx, hipEventSynchronize(t.b));
+        HIPCHK(ctx, hipEventElapsedTime(&d, t.a, t.b));
+        ctx->acc_ms[t.cls] += d;
+        ctx->acc_flops[t.cls] += t.flops;
+        ctx->acc_launches[t.cls] += 1;
+    }
+    ctx->timed.clear();
+    ctx->ev_used = 0;
+    ctx->timed_valid = false;
+    return NST_OK;
 }
 
 int bind(nst_ctx* ctx) {
@@ -508,6 +538,7 @@ int nst_closure(nst_ctx* ctx, const float* x, float cw, float sw, float tvw, flo
     for (int i = 0; i < ctx->levels; ++i)
         if (!ctx->lv[i].targets) return fail(ctx, NST_E_STATE, "targets of level " + std::to_string(i) + " not set");
     hipStream_t main = static_cast<hipStream_t>(stream);
+    if (ctx->timing >= 2) NSTCHK(fold_timed(ctx));
     ctx->timed.clear();
     ctx->ev_used = 0;
     ctx->timed_valid = false;
@@ -602,6 +633,37 @@ int nst_last_closure_class(nst_ctx* ctx, int cls, float* ms, int* launches, doub
         HIPCHK(ctx, hipEventSynchronize(t.b));
         HIPCHK(ctx, hipEventElapsedTime(&d, t.a, t.b));
         *ms += d; *launches += 1; *flops += t.flops;
+    }
+    return NST_OK;
+}
+
+// debugging aid: one line per timed launch of the last closure to stderr
+int nst_dump_last_closure(nst_ctx* ctx) {
+    NSTCHK(bind(ctx));
+    if (!ctx->timed_valid) return NST_OK;
+    HIPCHK(ctx, hipEventSynchronize(ctx->t1));
+    for (const TimedLaunch& t : ctx->timed) {
+        float d = 0.f;
+        HIPCHK(ctx, hipEventSynchronize(t.b));
+        HIPCHK(ctx, hipEventElapsedTime(&d, t.a, t.b));
+        fprintf(stderr, "cls %d  %4dx%-4d cin %3d cout %3d taps %d layer %3d  %8.3f ms  %7.2f TFLOP/s\n", t.cls, t.tag[0],
+                t.tag[1], t.tag[2], t.tag[3], t.tag[4], t.tag[5], d, d > 0 ? t.flops / (d * 1e-3) / 1e12 : 0.0);
+    }
+    return NST_OK;
+}
+
+// totals since the last reset (timing mode 2): per kernel class cls in 0..3 (0 = 3x3 MFMA conv fwd+dgrad,
+// 1 = Gram forward + its 1x1 backward, 2 = conv1_1 fwd+dgrad, 3 = streaming kernels); cls = -1: whole closures
+// (ms = summed closure wall on the caller's stream, launches = closures).  reset != 0 clears afterwards.
+int nst_timing_totals(nst_ctx* ctx, int cls, double* ms, long* launches, double* flops, int reset) {
+    NSTCHK(bind(ctx));
+    if (!ms || !launches || !flops || cls < -1 || cls >= K_NCLASS) return fail(ctx, NST_E_ARG, "bad argument");
+    NSTCHK(fold_timed(ctx));
+    if (cls < 0) { *ms = ctx->acc_closure_ms; *launches = ctx->acc_closures; *flops = 0; }
+    else { *ms = ctx->acc_ms[cls]; *launches = ctx->acc_launches[cls]; *flops = ctx->acc_flops[cls]; }
+    if (reset) {
+        for (int i = 0; i < 4; ++i) { ctx->acc_ms[i] = 0; ctx->acc_flops[i] = 0; ctx->acc_launches[i] = 0; }
+        ctx->acc_closure_ms = 0; ctx->acc_closures = 0;
     }
     return NST_OK;
 }

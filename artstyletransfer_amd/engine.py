@@ -122,6 +122,13 @@ class StyleEngine:
                    "nst_last_closure_class")
         return ms.value, n.value, fl.value
 
+    def timing_totals(self, cls: int, reset: bool = False):
+        """(ms, launches, flops) accumulated since the last reset; cls -1 = whole closures."""
+        ms, n, fl = C.c_double(), C.c_long(), C.c_double()
+        _lib.check(self.ctx, self.lib.nst_timing_totals(self.ctx, cls, C.byref(ms), C.byref(n), C.byref(fl),
+                                                        int(reset)), "nst_timing_totals")
+        return ms.value, n.value, fl.value
+
     # ---- standalone pieces (unit parity) ----------------------------------------------------------
     def vgg_features(self, x: torch.Tensor) -> List[torch.Tensor]:
         x = x.reshape(3, x.shape[-2], x.shape[-1])

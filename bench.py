@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Benchmark of the pyramid style-transfer hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one closure evaluation (the reference's `step` counter, neural_style_transfer.py:198)
+of the BASELINE workload - L=2: levels 1536x1024 + 768x512 + 384x256, synthetic 3:2 images,
+seeded synthetic VGG19 weights, content+noise init, L-BFGS as the reference constructs it - run
+through the optimiser driver, i.e. K closures = K/2 `optimizer.step(closure)` turns, each followed
+by the per-step image yield (unprepare + D2H) exactly as NeuralStyleTransfer.process does.
+Everything the step reads is resident in HBM before the timed region starts.
+
+N > 1 (launched with torch.distributed.run, one rank per GPU): every rank optimises an independent
+content x style job of the same shape (BASELINE config 5, task_executor throughput mode); there is
+no data-path collective, `value` is the whole-node closure rate, scaling is weak.
+
+Prints ONE JSON line (rank 0)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 flop/clk (v_mfma_f32_32x32x2_f32)
+
+
+def build_job(levels_num: int, seed_shift: int, device):
+    from artstyletransfer_amd import host_image, synthetic
+    from artstyletransfer_amd.engine import StyleEngine
+
+    base_h, base_w = 256, 384
+    top = levels_num - 1
+    H, W = base_h << top, base_w << top
+    content = synthetic.image(H, W, seed=1 + 2 * seed_shift)
+    style = synthetic.image(H, W, seed=2 + 2 * seed_shift)
+    content_levels = [host_image.resize_to_level(content, l) for l in range(top, -1, -1)]
+    style_levels = [host_image.resize_to_level(style, l) for l in range(top, -1, -1)]
+    from artstyletransfer_amd.config import Config
+    cfg = Config(levels_num=levels_num)
+    np.random.seed(0)
+    init, _ = host_image.initial_image(cfg.init_method, content, style, content_levels[0], style_levels[0], top,
+                                       cfg.noise_factor, cfg.noise_levels, cfg.noise_levels_central_amplitude,
+                                       cfg.noise_levels_peripheral_amplitude, cfg.noise_levels_dispersion)
+    weights = synthetic.vgg19_weights()
+    eng = StyleEngine(weights, device)
+    eng.configure(levels_num, H, W)
+    for l in range(levels_num):
+        c = eng.prepare_img(torch.from_numpy(content_levels[l]).to(eng.device))
+        s = eng.prepare_img(torch.from_numpy(style_levels[l]).to(eng.device))
+        eng.set_targets(l, c, s)
+    x = eng.prepare_img(torch.from_numpy(np.ascontiguousarray(init, dtype=np.float32)).to(eng.device))
+    return eng, x, cfg, (content_levels, style_levels, init, weights)
+
+
+def cpu_baseline(job_host, cfg, closures: int):
+    """The oracle (CPU restatement of the reference, validated against it in tests/) timed on this box's
+    host cores on a bounded sample of the same workload, run as the reference runs (anomaly mode, the
+    zero-weighted randn per level)."""
+    from oracle import cpu_ref
+    content_levels, style_levels, init, weights = job_host
+    # a 1-GPU box owns a 16-core share of a much larger host: more threads than that only thrash
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    threads = int(os.environ.get("NST_CPU_THREADS", min(avail, 16)))
+    torch.set_num_threads(threads)
+    t0 = time.perf_counter()
+    done = 0
+    for _img, step in cpu_ref.run_process(content_levels, style_levels, init, weights, cfg.optimizer, closures,
+                                          cfg.content_weight, cfg.style_weight, cfg.tv_weight, as_reference=True):
+        done = step
+    total = time.perf_counter() - t0
+    return {"value": done / total, "unit": "iters/s", "cores": threads, "kind": "port",
+            "sample": f"{done} closure evaluations of the same L={len(content_levels) - 1} job (the 2 target "
+                      f"forwards per level included), oracle run as the reference runs (anomaly mode on)",
+            "seconds": round(total, 2)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40, help="closure evaluations in the timed region (even)")
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--levels", type=int, default=3, help="levels_num (3 = BASELINE L=2)")
+    ap.add_argument("--optimizer", default="lbfgs", choices=["lbfgs", "adam"])
+    ap.add_argument("--no-yield", action="store_true", help="skip the per-step image yield (unprepare + D2H)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-closures", type=int, default=2)
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from artstyletransfer_amd.engine import PixelOptimizer
+    eng, x, cfg, job_host = build_job(args.levels, rank, local_rank)
+    cfg.optimizer = args.optimizer
+    opt = PixelOptimizer(eng, args.optimizer, 10.0, 1)
+    cw, sw, tvw = cfg.content_weight, cfg.style_weight, cfg.tv_weight
+    H, W = eng.shape
+    img_dev = None
+    img_host = torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True)
+    per_step = 2 if args.optimizer == "lbfgs" else 1
+
+    def run(closures: int):
+        done = 0
+        last = None
+        while done < closures:
+            info, rows = opt.step(x, cw, sw, tvw, want_losses=True)
+            done += info.closures
+            last = rows
+            if not args.no_yield:
+                img_host.copy_(eng.unprepare_img(x), non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+        return done, last
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    steps = max(per_step, (args.steps // per_step) * per_step)
+    run(max(args.warmup, 0))
+    if not args.no_kernel_timing:
+        eng.set_timing(2)
+        eng.timing_totals(0, reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    done, last_rows = run(steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        dd = torch.tensor([done], dtype=torch.float64, device="cuda")
+        dist.all_reduce(dd, op=dist.ReduceOp.SUM)
+        total_done = int(dd.item())
+    else:
+        total_done = done
+
+    if rank == 0:
+        px = sum((H >> l) * (W >> l) for l in range(args.levels))
+        closure_flops = 1514240.0 * px                        # conv fwd+dgrad + Gram fwd+bwd
+        out = {
+            "metric": "style-transfer iters/sec at L=2 (1024-px)" if args.levels == 3 else f"style-transfer iters/sec at L={args.levels - 1}",
+            "value": total_done / dt,
+            "unit": "iters/s",
+            "n_gpus": world,
+            "steps": done,
+            "warmup": args.warmup,
+            "ms_per_step": dt / done * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"pyramid style transfer, levels_num={args.levels} "
+                                   f"({'+'.join(f'{W >> l}x{H >> l}' for l in range(args.levels))}), "
+                                   f"{args.optimizer} as the reference constructs it, content+noise init, "
+                                   f"seeded synthetic VGG19 weights, per-step image yield "
+                                   f"{'off' if args.no_yield else 'on'}",
+                       "iter": "one closure evaluation (forward + losses + backward of every level) + its share of the optimiser update",
+                       "parallelism": "1 job per GPU, no collective" if world > 1 else "1 GPU",
+                       "final_loss": float(last_rows[-1][-1]) if last_rows is not None else None},
+            "closure_tflops_algorithmic": closure_flops / 1e12,
+            "closure_rate_tflops": closure_flops * (done / dt) / 1e12,
+        }
+        if not args.no_kernel_timing:
+            ms, n, fl = eng.timing_totals(0)
+            cms, cn, _ = eng.timing_totals(-1)
+            gms, gn, gfl = eng.timing_totals(1)
+            oms, on, _ = eng.timing_totals(3)
+            c1ms, c1n, c1fl = eng.timing_totals(2)
+            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel (3x3 fp32 MFMA conv, forward + input gradient)",
+                               "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                               "launches": n, "avg_launch_ms": ms / max(n, 1),
+                               "flops_per_launch_avg": fl / max(n, 1)}
+            out["kernel_ms_per_closure"] = {
+                "closure": cms / max(cn, 1), "conv3x3_mfma": ms / max(cn, 1), "gram_mfma": gms / max(cn, 1),
+                "conv1_1": c1ms / max(cn, 1), "streaming": oms / max(cn, 1)}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(job_host, cfg, args.cpu_closures)
+        print(json.dumps(out), flush=True)
+    opt.close()
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

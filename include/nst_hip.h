@@ -128,8 +128,17 @@ int nst_ctx_bytes(const nst_ctx* ctx, size_t* bytes);
 
 /* wall time in ms of the kernels of the last nst_closure on `ctx`, measured with HIP events on
  * the streams the kernels ran on (0 if timing was not enabled with nst_set_timing). */
-int nst_set_timing(nst_ctx* ctx, int enabled);
+int nst_set_timing(nst_ctx* ctx, int enabled);   /* 0 off, 1 whole closure, 2 + every kernel launch */
 int nst_last_closure_ms(nst_ctx* ctx, float* ms);
+/* last closure, per kernel class: summed launch durations (ms), launches, algorithmic flops.
+ * cls: 0 = 3x3 MFMA convolutions (forward + input gradient), 1 = Gram forward + its 1x1 backward,
+ * 2 = conv1_1 forward + input gradient, 3 = streaming kernels (pool, bicubic, TV, MSE, reductions). */
+int nst_last_closure_class(nst_ctx* ctx, int cls, float* ms, int* launches, double* flops);
+/* the same accumulated over every closure since the last reset (timing mode 2); cls = -1: whole
+ * closures (ms = summed closure time on the caller's stream, launches = closures). */
+int nst_timing_totals(nst_ctx* ctx, int cls, double* ms, long* launches, double* flops, int reset);
+/* debugging aid: prints one line per timed launch of the last closure (timing mode 2) to stderr */
+int nst_dump_last_closure(nst_ctx* ctx);
 
 #ifdef __cplusplus
 }
