@@ -102,24 +102,45 @@ hipError_t launch_conv1_1_fwd(const float* x, int H, int W, const float* wk, con
 }
 
 // Input gradient of conv1_1: gx[c][y][x] = sum_{tap, co} g[y+dy-1][x+dx-1][co] * wd[tap][co][c]
-// (wd holds the tap-flipped weights).  One pixel per lane, three accumulators; the weights are
-// wave-uniform and come through the scalar path.
+// (wd holds the tap-flipped weights).  N = 3 output channels is no MFMA shape (a 32-wide tile would
+// waste 29/32 of the matrix pipe), so this runs on the VALU: one pixel per lane, three accumulators,
+// the 64-channel gradient of the 18x18 halo patch staged through LDS in two 32-channel slices
+// (144-B rows: conflict-light ds_read_b128), weights wave-uniform through the scalar path.
+namespace {
+constexpr int D_T = 16;                    // 16 x 16 pixel tile, 256 threads
+constexpr int D_P = D_T + 2;
+constexpr int D_KC = 32;
+constexpr int D_RS = D_KC + 4;             // LDS row stride (floats)
+constexpr int D_UNITS = D_P * D_P * (D_KC / 4);
+}  // namespace
+
 __global__ __launch_bounds__(256) void conv1_1_dgrad_kernel(const float* __restrict__ g, int H, int W,
                                                             const float* __restrict__ wd, float* __restrict__ gx) {
-    const size_t HW = (size_t)H * W;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (size_t)gridDim.x * blockDim.x) {
-        const int xx = (int)(i % W);
-        const int y = (int)(i / W);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    __shared__ __attribute__((aligned(16))) float patch[D_P * D_P * D_RS];
+    const int tid = threadIdx.x;
+    const int tiles_x = (W + D_T - 1) / D_T;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
+    const int y0 = ty * D_T, x0 = tx * D_T;
+    const int py = tid >> 4, px = tid & 15;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int chunk = 0; chunk < 64 / D_KC; ++chunk) {
+        if (chunk) __syncthreads();
+        for (int u = tid; u < D_UNITS; u += 256) {
+            const int pix = u / (D_KC / 4), q = u % (D_KC / 4);
+            const int gy = y0 - 1 + pix / D_P, gxx = x0 - 1 + pix % D_P;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (gy >= 0 && gy < H && gxx >= 0 && gxx < W)
+                v = *reinterpret_cast<const f32x4*>(g + ((size_t)gy * W + gxx) * 64 + chunk * D_KC + q * 4);
+            *reinterpret_cast<f32x4*>(patch + pix * D_RS + q * 4) = v;
+        }
+        __syncthreads();
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int sy = y + t / 3 - 1, sx = xx + t % 3 - 1;
-            if (sy < 0 || sy >= H || sx < 0 || sx >= W) continue;
-            const f32x4* src = reinterpret_cast<const f32x4*>(g + ((size_t)sy * W + sx) * 64);
-            const f32x4* wv = reinterpret_cast<const f32x4*>(wd + t * 64 * 4);
+            const float* row = patch + ((py + t / 3) * D_P + px + t % 3) * D_RS;
+            const f32x4* wv = reinterpret_cast<const f32x4*>(wd + (t * 64 + chunk * D_KC) * 4);
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const f32x4 v = src[q];
+            for (int q = 0; q < D_KC / 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(row + q * 4);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const f32x4 w = wv[q * 4 + k];
@@ -129,6 +150,10 @@ __global__ __launch_bounds__(256) void conv1_1_dgrad_kernel(const float* __restr
                 }
             }
         }
+    }
+    const int y = y0 + py, x = x0 + px;
+    if (y < H && x < W) {
+        const size_t HW = (size_t)H * W, i = (size_t)y * W + x;
         gx[i] = a0;
         gx[HW + i] = a1;
         gx[2 * HW + i] = a2;
@@ -136,10 +161,8 @@ __global__ __launch_bounds__(256) void conv1_1_dgrad_kernel(const float* __restr
 }
 
 hipError_t launch_conv1_1_dgrad(const float* g, int H, int W, const float* wd, float* gx, hipStream_t stream) {
-    const size_t HW = (size_t)H * W;
-    size_t blocks = (HW + 255) / 256;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(conv1_1_dgrad_kernel, dim3((int)blocks), dim3(256), 0, stream, g, H, W, wd, gx);
+    const int blocks = ((H + D_T - 1) / D_T) * ((W + D_T - 1) / D_T);
+    hipLaunchKernelGGL(conv1_1_dgrad_kernel, dim3(blocks), dim3(256), 0, stream, g, H, W, wd, gx);
     return hipGetLastError();
 }
 

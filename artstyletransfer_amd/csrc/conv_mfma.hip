@@ -74,7 +74,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int x0 = tx * C::TW;
     const int n0 = ct * BN;
 
-    const int nchunks = p.Cin / KC;
+    // split-K: blockIdx.y owns the channel chunks [c_begin, c_end)
+    const int nchunks_all = p.Cin / KC;
+    const int cps = nchunks_all / p.ksplit;
+    const int c_begin = blockIdx.y * cps;
+    const int c_end = c_begin + cps;
 
     f32x4 ra[C::A_PER_T];
     f32x4 rb[C::B_PER_T];
@@ -147,11 +151,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     const int b_off0 = (wn * 64 + l31) * C::BS + 4 * half;
     const int b_off1 = (wn * 64 + 32 + l31) * C::BS + 4 * half;
 
-    load_a(0);
-    load_b(0, 0);
+    load_a(c_begin);
+    load_b(c_begin, 0);
     int cur = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        if (c > 0) __syncthreads();     // every wave is done reading the previous patch
+    for (int c = c_begin; c < c_end; ++c) {
+        if (c > c_begin) __syncthreads();     // every wave is done reading the previous patch
         store_a();
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
             __syncthreads();
             if (t + 1 < TAPS) {
                 load_b(c, t + 1);
-            } else if (c + 1 < nchunks) {
+            } else if (c + 1 < c_end) {
                 load_b(c + 1, 0);
                 load_a(c + 1);
             }
@@ -186,6 +190,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     }
 
     // epilogue: D[m][n]: n = lane&31, m = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (p.ksplit > 1) {
+        // raw partial sums; conv_splitk_finish_kernel adds them in split order and applies the epilogue
+        float* dst = p.partial + (size_t)blockIdx.y * p.H * p.W * p.Cout;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = n0 + wn * 64 + nt * 32 + l31;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int y = y0 + wm * 4 + mt * 2 + (m >> 4);
+                    const int x = x0 + (m & 15);
+                    if (y < p.H && x < p.W) dst[((size_t)y * p.W + x) * p.Cout + co] = acc[mt][nt][r];
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int co = n0 + wn * 64 + nt * 32 + l31;
@@ -210,14 +233,78 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvParams p) {
     }
 }
 
+// out = sum_s partial[s] (+ bias) (+ addend) (ReLU) (mask), 16 bytes per lane
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(ConvParams p) {
+    const size_t n4 = (size_t)p.H * p.W * p.Cout / 4;
+    const int c4 = p.Cout / 4;
+    const f32x4* part = reinterpret_cast<const f32x4*>(p.partial);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 v = part[i];
+        for (int s = 1; s < p.ksplit; ++s) {
+            const f32x4 t = part[(size_t)s * n4 + i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += t[k];
+        }
+        if (p.bias) {
+            const f32x4 b = reinterpret_cast<const f32x4*>(p.bias)[i % c4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += b[k];
+        }
+        if (p.addend) {
+            const f32x4 a = reinterpret_cast<const f32x4*>(p.addend)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] += a[k];
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (p.mask) {
+            const f32x4 m = reinterpret_cast<const f32x4*>(p.mask)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = (m[k] > 0.f) ? v[k] : 0.f;
+        }
+        reinterpret_cast<f32x4*>(p.out)[i] = v;
+    }
+}
+
+// Split the channel chunks over S blocks when the (spatial x channel) tiles alone cannot fill the chip.
+// cost(S) = waves of blocks over the 256 CUs x chunks per block; smallest S within 5 % of the best.
+int conv_ksplit(int H, int W, int Cin, int Cout) {
+    const bool wide = (Cout % 128 == 0);
+    const int th = wide ? 8 : 16, bn = wide ? 128 : 64;
+    const long blocks = (long)((H + th - 1) / th) * ((W + 15) / 16) * (Cout / bn);
+    const int nchunks = Cin / 32;
+    if (blocks >= 384 || nchunks < 2) return 1;
+    double best = 1e30;
+    for (int S = 1; S <= nchunks && S <= 16; S *= 2) {
+        if (nchunks % S) continue;
+        const double c = (double)((blocks * S + 255) / 256) * (nchunks / S);
+        if (c < best) best = c;
+    }
+    for (int S = 1; S <= nchunks && S <= 16; S *= 2) {
+        if (nchunks % S) continue;
+        const double c = (double)((blocks * S + 255) / 256) * (nchunks / S);
+        if (c <= best * 1.05) return S;
+    }
+    return 1;
+}
+
 template <int TH, int BN, int KC, int TAPS>
 static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
     using C = ConvCfg<TH, BN, KC, TAPS>;
     ConvParams p = p0;
     p.tiles_x = (p.W + C::TW - 1) / C::TW;
     p.tiles_y = (p.H + TH - 1) / TH;
+    if (p.ksplit < 1) p.ksplit = 1;
     const int blocks = p.tiles_x * p.tiles_y * (p.Cout / BN);
-    hipLaunchKernelGGL((conv_mfma_kernel<TH, BN, KC, TAPS>), dim3(blocks), dim3(C::NT), C::LDS_BYTES, stream, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<TH, BN, KC, TAPS>), dim3(blocks, p.ksplit), dim3(C::NT), C::LDS_BYTES, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || p.ksplit == 1) return e;
+    const size_t n4 = (size_t)p.H * p.W * p.Cout / 4;
+    size_t fb = (n4 + 255) / 256;
+    if (fb > 2048) fb = 2048;
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((int)fb), dim3(256), 0, stream, p);
     return hipGetLastError();
 }
 
@@ -239,8 +326,14 @@ hipError_t conv_mfma_init_device() {
 }
 
 // Shapes must satisfy Cin % 32 == 0 and Cout % 64 == 0 (all VGG19 layers but conv1_1).
-hipError_t launch_conv_mfma(const ConvParams& p, int taps, hipStream_t stream) {
-    if (p.Cin % 32 != 0 || p.Cout % 64 != 0 || (taps != 9 && taps != 1)) return hipErrorInvalidValue;
+hipError_t launch_conv_mfma(const ConvParams& p0, int taps, hipStream_t stream) {
+    if (p0.Cin % 32 != 0 || p0.Cout % 64 != 0 || (taps != 9 && taps != 1)) return hipErrorInvalidValue;
+    ConvParams p = p0;
+    p.ksplit = 1;
+    if (taps == 9 && p.partial) {
+        const int S = conv_ksplit(p.H, p.W, p.Cin, p.Cout);
+        if (S > 1 && (size_t)S * p.H * p.W * p.Cout <= p.partial_floats) p.ksplit = S;
+    }
     const bool wide = (p.Cout % 128 == 0);
     if (taps == 9) {
         if (wide) return launch_cfg<8, 128, 32, 9>(p, stream);

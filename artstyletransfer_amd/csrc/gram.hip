@@ -215,46 +215,58 @@ hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, floa
     return hipGetLastError();
 }
 
-__device__ __forceinline__ double block_sum_256(double v, double* sh) {
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    double r = 0.0;
-    if (threadIdx.x == 0) r = ((sh[0] + sh[1]) + sh[2]) + sh[3];
-    __syncthreads();
-    return r;
-}
-
+// G = (sum of the slabs, in slab order) / divisor; optional target: S = coef * (G - Gt) and the partial sums
+// of (G - Gt)^2.  A block owns 32 consecutive elements; its 8 lane groups each add every 8th slab, then the
+// 8 group sums are added in group order - a fixed order, so the result is reproducible.
 __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ part, int nslabs, int C, int ts,
                                                           float divisor, const float* __restrict__ target, float coef,
                                                           float* __restrict__ gram_out, float* __restrict__ S,
                                                           double* __restrict__ mse_partial) {
-    __shared__ double sh[4];
+    __shared__ float sh[8][32];
+    __shared__ double shd[32];
     const size_t CC = (size_t)C * C;
-    double sq = 0.0;
-    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < CC; e += (size_t)gridDim.x * blockDim.x) {
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const size_t e = (size_t)blockIdx.x * 32 + el;
+    float s = 0.f;
+    if (e < CC) {
         const int i = (int)(e / C), j = (int)(e % C);
         // tiles below the diagonal were not computed: read the mirrored element
         size_t src = e;
         if (ts > 0 && (i / ts) > (j / ts)) src = (size_t)j * C + i;
-        float s = 0.f;
-        for (int k = 0; k < nslabs; ++k) s += part[(size_t)k * CC + src];
-        const float g = s / divisor;      // torch: gram /= ch*h*w
-        if (gram_out) gram_out[e] = g;
-        if (target) {
-            const float d = g - target[e];
-            sq += (double)d * (double)d;
-            if (S) S[e] = coef * d;
-        }
+        for (int k = grp; k < nslabs; k += 8) s += part[(size_t)k * CC + src];
     }
-    const double b = block_sum_256(sq, sh);
-    if (mse_partial && threadIdx.x == 0) mse_partial[blockIdx.x] = b;
+    sh[grp][el] = s;
+    __syncthreads();
+    if (grp == 0) {
+        float t = sh[0][el];
+#pragma unroll
+        for (int g = 1; g < 8; ++g) t += sh[g][el];
+        double sq = 0.0;
+        if (e < CC) {
+            const float g = t / divisor;      // torch: gram /= ch*h*w
+            if (gram_out) gram_out[e] = g;
+            if (target) {
+                const float d = g - target[e];
+                sq = (double)d * (double)d;
+                if (S) S[e] = coef * d;
+            }
+        }
+        shd[el] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && mse_partial) {
+        double t = 0.0;
+        for (int k = 0; k < 32; ++k) t += shd[k];
+        mse_partial[blockIdx.x] = t;
+    }
 }
+
+int gram_finish_blocks(int C) { return (int)(((size_t)C * C + 31) / 32); }
 
 hipError_t launch_gram_finish(const float* part, int nslabs, int C, float divisor, const float* target, float coef,
                               float* gram_out, float* S, double* mse_partial, hipStream_t stream) {
-    hipLaunchKernelGGL(gram_finish_kernel, dim3(GRAM_FIN_BLOCKS), dim3(256), 0, stream, part, nslabs, C, gram_ts(C),
-                       divisor, target, coef, gram_out, S, mse_partial);
+    hipLaunchKernelGGL(gram_finish_kernel, dim3(gram_finish_blocks(C)), dim3(256), 0, stream, part, nslabs, C,
+                       gram_ts(C), divisor, target, coef, gram_out, S, mse_partial);
     return hipGetLastError();
 }
 

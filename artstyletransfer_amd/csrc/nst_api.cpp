@@ -35,6 +35,8 @@ struct ActSet {                 // activations of one forward pass, NHWC
     int h[NL], w[NL];
     float* act[NL] = {};
     float* pool[4] = {};
+    float* splitk = nullptr;     // split-K partial sums of the small-spatial conv layers
+    size_t splitk_floats = 0;
     size_t bytes = 0;
 };
 
@@ -142,11 +144,25 @@ int alloc_acts(nst_ctx* ctx, ActSet& a, int h, int w) {
         NSTCHK(dev_alloc_t(ctx, &a.pool[k], n));
         a.bytes += n * 4;
     }
+    size_t need = 0;
+    for (int l = 1; l < NL; ++l) {
+        const size_t px = (size_t)a.h[l] * a.w[l];
+        const size_t fwd = (size_t)conv_ksplit(a.h[l], a.w[l], kCin[l], kCout[l]) * px * kCout[l];
+        const size_t bwd = (size_t)conv_ksplit(a.h[l], a.w[l], kCout[l], kCin[l]) * px * kCin[l];
+        if (fwd > px * kCout[l] && fwd > need) need = fwd;
+        if (bwd > px * kCin[l] && bwd > need) need = bwd;
+    }
+    a.splitk_floats = need;
+    if (need) {
+        NSTCHK(dev_alloc_t(ctx, &a.splitk, need));
+        a.bytes += need * 4;
+    }
     return NST_OK;
 }
 void free_acts(nst_ctx* ctx, ActSet& a) {
     for (int l = 0; l < NL; ++l) { dev_free(a.act[l]); a.act[l] = nullptr; }
     for (int k = 0; k < 4; ++k) { dev_free(a.pool[k]); a.pool[k] = nullptr; }
+    dev_free(a.splitk); a.splitk = nullptr; a.splitk_floats = 0;
     if (ctx->bytes >= a.bytes) ctx->bytes -= a.bytes;
     a.bytes = 0;
 }
@@ -188,6 +204,7 @@ int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s
         ConvParams p{};
         p.in = in; p.wt = ctx->wf[l]; p.bias = ctx->bias[l]; p.addend = nullptr; p.mask = nullptr; p.out = a.act[l];
         p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCin[l]; p.Cout = kCout[l]; p.relu = 1;
+        p.partial = a.splitk; p.partial_floats = a.splitk_floats;
         {
             Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, l);
             HIPCHK(ctx, launch_conv_mfma(p, 9, s));
@@ -240,6 +257,7 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
         ConvParams p{};
         p.in = cur; p.wt = ctx->wd[l]; p.out = oth;
         p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCout[l]; p.Cout = kCin[l];
+        p.partial = a.splitk; p.partial_floats = a.splitk_floats;
         if (pk >= 0) {
             {
                 Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, -l);
@@ -473,7 +491,7 @@ int nst_job_configure(nst_ctx* ctx, int levels_num, int H0, int W0) {
             const int C = kCout[kStyleLayer[k]];
             NSTCHK(dev_alloc_t(ctx, &L.gram_t[k], (size_t)C * C));
             NSTCHK(dev_alloc_t(ctx, &L.S[k], (size_t)C * C));
-            NSTCHK(dev_alloc_t(ctx, &L.style_partial[k], GRAM_FIN_BLOCKS));
+            NSTCHK(dev_alloc_t(ctx, &L.style_partial[k], gram_finish_blocks(C)));
         }
         L.gram_part_floats = gram_part_floats_for(h, w);
         NSTCHK(dev_alloc_t(ctx, &L.gram_part, L.gram_part_floats));

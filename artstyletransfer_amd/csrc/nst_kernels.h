@@ -18,11 +18,16 @@ struct ConvParams {
     int H, W, Cin, Cout;
     int relu;
     int tiles_x, tiles_y; // filled by the launcher
+    float* partial;       // split-K workspace (nullable): [ksplit][H][W][Cout]
+    size_t partial_floats;
+    int ksplit;           // filled by the launcher
 };
 
 // conv_mfma.hip
 hipError_t conv_mfma_init_device();
 hipError_t launch_conv_mfma(const ConvParams& p, int taps, hipStream_t stream);
+// number of channel-chunk splits launch_conv_mfma uses for a 3x3 layer of this shape (1 = none)
+int conv_ksplit(int H, int W, int Cin, int Cout);
 
 // conv_first.hip: conv1_1 (3 -> 64) forward from the planar image, and its input gradient
 // wk: [28][64] (k = c*9 + ky*3 + kx, row 27 zero); bias [64]; out NHWC 64, ReLU applied.
@@ -70,12 +75,11 @@ hipError_t launch_mse_grad(const float* a, const float* t, size_t n, float coef,
 hipError_t launch_prepare_img(const float* hwc, int h, int w, float* chw, hipStream_t stream);
 hipError_t launch_unprepare_img(const float* chw, int h, int w, float* hwc, hipStream_t stream);
 
-constexpr int GRAM_FIN_BLOCKS = 64;
 // loss assembly -----------------------------------------------------------------------------------
 struct LevelLossInputs {
     const double* content_partial;   // MSE_BLOCKS doubles
     size_t content_n;
-    const double* style_partial[5];  // GRAM_FIN_BLOCKS doubles each: partial sums of (G-Gt)^2
+    const double* style_partial[5];  // gram_finish_blocks(C) doubles each: partial sums of (G-Gt)^2
     int style_c[5];                  // C of each style layer (mse mean over C*C)
     const float* tv_means;           // 2 floats (mean_x, mean_y)
 };
@@ -94,8 +98,9 @@ int gram_nsplit(int C, size_t N);
 hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, float* part, hipStream_t stream);
 // G = (sum_s part[s]) / divisor (fixed order).  If target: mse_out[0] = sum((G-Gt)^2) (double) and
 // S = coef * (G - Gt) (C x C, for the backward 1x1 conv).  gram_out / target / S / mse_partial nullable;
-// mse_partial: GRAM_FIN_BLOCKS doubles.  `nslabs` = gram_nslabs(C, nsplit).
+// mse_partial: gram_finish_blocks(C) doubles.  `nslabs` = gram_nslabs(C, nsplit).
 int gram_nslabs(int C, int nsplit);
+int gram_finish_blocks(int C);
 hipError_t launch_gram_finish(const float* part, int nslabs, int C, float divisor, const float* target, float coef,
                               float* gram_out, float* S, double* mse_partial, hipStream_t stream);
 

@@ -441,8 +441,13 @@ __global__ __launch_bounds__(256) void loss_assemble_kernel(LossAssembly la) {
         const LevelLossInputs& in = la.lv[l];
         const double cs = block_reduce_sum(threadIdx.x < MSE_BLOCKS ? in.content_partial[threadIdx.x] : 0.0, sh);
         double ss[5];
-        for (int k = 0; k < 5; ++k)
-            ss[k] = block_reduce_sum(threadIdx.x < GRAM_FIN_BLOCKS ? in.style_partial[k][threadIdx.x] : 0.0, sh);
+        for (int k = 0; k < 5; ++k) {
+            // C*C/32 partials: each thread adds its strided share in index order, then the fixed tree
+            const int nb = (in.style_c[k] * in.style_c[k] + 31) / 32;
+            double t = 0.0;
+            for (int b = threadIdx.x; b < nb; b += 256) t += in.style_partial[k][b];
+            ss[k] = block_reduce_sum(t, sh);
+        }
         if (threadIdx.x == 0) {
             const float content = (float)(cs / (double)in.content_n);
             float style = 0.f;
