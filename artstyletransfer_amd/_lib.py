@@ -21,6 +21,7 @@ NST_OPT_ADAM = 0
 NST_OPT_LBFGS = 1
 
 c_float_p = C.POINTER(C.c_float)
+REDUCE_HOOK = C.CFUNCTYPE(None, C.c_void_p)
 c_void = C.c_void_p
 
 
@@ -39,6 +40,8 @@ SYMBOLS = {
     "nst_job_configure": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int]),
     "nst_level_set_targets": (C.c_int, [c_void, C.c_int, c_void, c_void, C.c_int, C.c_int, c_void]),
     "nst_closure": (C.c_int, [c_void, c_void, C.c_float, C.c_float, C.c_float, c_void, c_void, c_void]),
+    "nst_closure_levels": (C.c_int, [c_void, c_void, C.c_float, C.c_float, C.c_float, C.c_uint, c_void, c_void, c_void]),
+    "nst_opt_shard_levels": (C.c_int, [c_void, C.c_uint, c_void, c_void, c_void, c_void]),
     "nst_opt_create": (C.c_int, [c_void, C.c_int, C.c_float, C.c_int, C.POINTER(c_void)]),
     "nst_opt_destroy": (None, [c_void]),
     "nst_opt_step": (C.c_int, [c_void, c_void, C.c_float, C.c_float, C.c_float, c_void, C.c_int,

@@ -550,11 +550,17 @@ int nst_set_timing(nst_ctx* ctx, int enabled) {
 }
 
 int nst_closure(nst_ctx* ctx, const float* x, float cw, float sw, float tvw, float* grad, float* losses, void* stream) {
+    return nst_closure_levels(ctx, x, cw, sw, tvw, 0xFFFFFFFFu, grad, losses, stream);
+}
+
+int nst_closure_levels(nst_ctx* ctx, const float* x, float cw, float sw, float tvw, unsigned level_mask, float* grad,
+                       float* losses, void* stream) {
     NSTCHK(bind(ctx));
     if (ctx->levels < 1) return fail(ctx, NST_E_STATE, "nst_job_configure has not been called");
     if (!x || !grad || !losses) return fail(ctx, NST_E_ARG, "null buffer");
     for (int i = 0; i < ctx->levels; ++i)
-        if (!ctx->lv[i].targets) return fail(ctx, NST_E_STATE, "targets of level " + std::to_string(i) + " not set");
+        if (((level_mask >> i) & 1u) && !ctx->lv[i].targets)
+            return fail(ctx, NST_E_STATE, "targets of level " + std::to_string(i) + " not set");
     hipStream_t main = static_cast<hipStream_t>(stream);
     if (ctx->timing >= 2) NSTCHK(fold_timed(ctx));
     ctx->timed.clear();
@@ -579,6 +585,12 @@ int nst_closure(nst_ctx* ctx, const float* x, float cw, float sw, float tvw, flo
         LevelWs& L = ctx->lv[i];
         hipStream_t s = multi ? L.stream : main;
         if (multi) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->fork, 0));
+        if (!((level_mask >> i) & 1u)) {
+            // a level another rank owns: it contributes nothing here (its gradient arrives by all-reduce)
+            HIPCHK(ctx, hipMemsetAsync(gi[i], 0, (size_t)3 * L.h * L.w * sizeof(float), s));
+            if (multi) HIPCHK(ctx, hipEventRecord(L.done, s));
+            continue;
+        }
         {
             Timer t(ctx, s, K_OTHER, 0);
             HIPCHK(ctx, launch_tv_partial(xi[i], 3, L.h, L.w, L.tv_partial, s));
@@ -622,6 +634,7 @@ int nst_closure(nst_ctx* ctx, const float* x, float cw, float sw, float tvw, flo
         la.lv[i].content_n = L.content_n;
         for (int k = 0; k < 5; ++k) { la.lv[i].style_partial[k] = L.style_partial[k]; la.lv[i].style_c[k] = kCout[kStyleLayer[k]]; }
         la.lv[i].tv_means = L.tv_means;
+        la.lv[i].owned = (int)((level_mask >> i) & 1u);
     }
     HIPCHK(ctx, launch_loss_assemble(la, main));
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->t1, main)); ctx->timed_valid = true; }

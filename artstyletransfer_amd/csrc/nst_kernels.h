@@ -82,6 +82,7 @@ struct LevelLossInputs {
     const double* style_partial[5];  // gram_finish_blocks(C) doubles each: partial sums of (G-Gt)^2
     int style_c[5];                  // C of each style layer (mse mean over C*C)
     const float* tv_means;           // 2 floats (mean_x, mean_y)
+    int owned;                       // 0: level computed by another rank, its row is written as zeros
 };
 struct LossAssembly {
     LevelLossInputs lv[8];

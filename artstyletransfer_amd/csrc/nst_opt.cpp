@@ -50,6 +50,11 @@ struct nst_opt {
     bool t_is_float = true;      // t held as fp32 tensor value vs python double
     double t = 0.0;
     bool have_prev = false;
+    // level sharding (BASELINE config 4)
+    unsigned level_mask = 0xFFFFFFFFu;
+    nst_reduce_hook hook = nullptr;
+    void* hook_user = nullptr;
+    float* own_g = nullptr; float* own_losses = nullptr;   // buffers this object allocated
     // per-step outputs
     std::vector<float> loss_rows;   // host copy of every closure's loss rows in this step
 };
@@ -77,7 +82,8 @@ int oalloc(nst_opt* o, float** p, size_t n) {
 // one closure evaluation at x: decays lr, fills o->g, returns the total loss (host) - synchronises
 int eval_closure(nst_opt* o, const float* x, float cw, float sw, float tvw, hipStream_t s, float* loss_out) {
     o->lr *= 0.999;                                                          // neural_style_transfer.py:155-158
-    OCHK(nst_closure(o->ctx, x, cw, sw, tvw, o->g, o->losses, s));
+    OCHK(nst_closure_levels(o->ctx, x, cw, sw, tvw, o->level_mask, o->g, o->losses, s));
+    if (o->hook) o->hook(o->hook_user);                                      // all-reduce(sum) over the ranks
     const size_t row = (size_t)NST_LOSS_ROW * o->levels + 1;
     const size_t off = o->loss_rows.size();
     o->loss_rows.resize(off + row);
@@ -307,6 +313,7 @@ int nst_opt_create(nst_ctx* ctx, int kind, float lr_start, int lbfgs_max_eval, n
     o->max_eval = lbfgs_max_eval < 1 ? 1 : lbfgs_max_eval;
     int r = oalloc(o, &o->g, o->n);
     if (r == NST_OK) r = oalloc(o, &o->losses, (size_t)NST_LOSS_ROW * o->levels + 1);
+    o->own_g = o->g; o->own_losses = o->losses;
     if (r == NST_OK) r = oalloc(o, &o->scal, 4);
     if (r == NST_OK && hipMalloc(reinterpret_cast<void**>(&o->scratch), 2 * RED_BLOCKS * sizeof(double)) != hipSuccess) r = NST_E_NOMEM;
     if (r == NST_OK && kind == NST_OPT_ADAM) {
@@ -329,13 +336,24 @@ void nst_opt_destroy(nst_opt* o) {
     if (!o) return;
     (void)hipSetDevice(nst_internal_device(o->ctx));
     (void)hipDeviceSynchronize();
-    float* ptrs[] = {o->g, o->losses, o->scal, o->m, o->v, o->d, o->prev_g, o->xinit, o->q};
+    float* ptrs[] = {o->own_g, o->own_losses, o->scal, o->m, o->v, o->d, o->prev_g, o->xinit, o->q};
     for (float* p : ptrs) if (p) (void)hipFree(p);
     if (o->scratch) (void)hipFree(o->scratch);
     for (float* p : o->old_dirs) (void)hipFree(p);
     for (float* p : o->old_stps) (void)hipFree(p);
     for (float* p : o->spare) (void)hipFree(p);
     delete o;
+}
+
+int nst_opt_shard_levels(nst_opt* o, unsigned level_mask, float* grad, float* losses, nst_reduce_hook hook, void* user) {
+    if (!o) return nst_internal_fail(nullptr, NST_E_ARG, "null optimiser");
+    if ((hook != nullptr) != (grad != nullptr && losses != nullptr))
+        return nst_internal_fail(o->ctx, NST_E_ARG, "a reduce hook needs caller-owned grad and losses buffers (and vice versa)");
+    o->level_mask = level_mask;
+    o->hook = hook; o->hook_user = user;
+    o->g = grad ? grad : o->own_g;
+    o->losses = losses ? losses : o->own_losses;
+    return NST_OK;
 }
 
 int nst_opt_step(nst_opt* o, float* x, float cw, float sw, float tvw, float* losses_host, int closures_capacity,
@@ -352,7 +370,8 @@ int nst_opt_step(nst_opt* o, float* x, float cw, float sw, float tvw, float* los
             OCHK(eval_closure(o, x, cw, sw, tvw, s, &loss));
         } else {
             o->lr *= 0.999;
-            OCHK(nst_closure(o->ctx, x, cw, sw, tvw, o->g, o->losses, s));
+            OCHK(nst_closure_levels(o->ctx, x, cw, sw, tvw, o->level_mask, o->g, o->losses, s));
+            if (o->hook) o->hook(o->hook_user);
             o->total_closures += 1;
         }
         o->k += 1;

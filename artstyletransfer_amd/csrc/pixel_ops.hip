@@ -437,8 +437,13 @@ __global__ __launch_bounds__(256) void loss_assemble_kernel(LossAssembly la) {
 #pragma clang fp contract(off)
     __shared__ double sh[4];
     __shared__ float tot;
+    bool first = true;
     for (int l = 0; l < la.levels; ++l) {
         const LevelLossInputs& in = la.lv[l];
+        if (!in.owned) {
+            if (threadIdx.x < 4) la.out[4 * l + threadIdx.x] = 0.f;
+            continue;
+        }
         const double cs = block_reduce_sum(threadIdx.x < MSE_BLOCKS ? in.content_partial[threadIdx.x] : 0.0, sh);
         double ss[5];
         for (int k = 0; k < 5; ++k) {
@@ -462,11 +467,12 @@ __global__ __launch_bounds__(256) void loss_assemble_kernel(LossAssembly la) {
             la.out[4 * l + 1] = content;
             la.out[4 * l + 2] = style;
             la.out[4 * l + 3] = tv;
-            tot = (l == 0) ? total : (1.0f * tot + total);
+            tot = first ? total : (1.0f * tot + total);
         }
+        first = false;
         __syncthreads();
     }
-    if (threadIdx.x == 0) la.out[4 * la.levels] = tot;
+    if (threadIdx.x == 0) la.out[4 * la.levels] = first ? 0.f : tot;
 }
 
 hipError_t launch_loss_assemble(const LossAssembly& la, hipStream_t stream) {

@@ -102,6 +102,19 @@ class StyleEngine:
                                                   _stream(self.device)), "nst_closure")
         return grad, losses
 
+    def closure_levels(self, x: torch.Tensor, cw: float, sw: float, tvw: float, mask: int,
+                       grad: Optional[torch.Tensor] = None, losses: Optional[torch.Tensor] = None):
+        """The closure restricted to the levels in `mask` (level sharding); see nst_closure_levels."""
+        H, W = self.shape
+        _chk_dev(x, self.device)
+        if grad is None:
+            grad = torch.empty((1, 3, H, W), dtype=torch.float32, device=self.device)
+        if losses is None:
+            losses = torch.empty(NST_LOSS_ROW * self.levels + 1, dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_closure_levels(self.ctx, _ptr(x), cw, sw, tvw, mask, _ptr(grad),
+                                                         _ptr(losses), _stream(self.device)), "nst_closure_levels")
+        return grad, losses
+
     def bytes(self) -> int:
         n = C.c_size_t()
         _lib.check(self.ctx, self.lib.nst_ctx_bytes(self.ctx, C.byref(n)), "nst_ctx_bytes")
@@ -224,6 +237,23 @@ class PixelOptimizer:
         self.row = NST_LOSS_ROW * engine.levels + 1
         self.cap = 32 if name == "lbfgs" else 1
         self._rows = np.zeros((self.cap, self.row), dtype=np.float32)
+
+    def shard_levels(self, rank: int, world: int, dist_mod=None, group=None) -> None:
+        """Level sharding (BASELINE config 4): this rank evaluates only its levels; after every closure
+        the partial gradient and loss rows are all-reduced (RCCL) before the driver reads them."""
+        from . import sharding
+        e = self.engine
+        H, W = e.shape
+        self._g = torch.zeros((1, 3, H, W), dtype=torch.float32, device=e.device)
+        self._l = torch.zeros(self.row, dtype=torch.float32, device=e.device)
+
+        def hook(_user):
+            sharding.allreduce_closure(self._g, self._l, dist_mod, group)
+
+        self._hook = _lib.REDUCE_HOOK(hook)          # keep the callback object alive
+        _lib.check(e.ctx, e.lib.nst_opt_shard_levels(self.h, sharding.level_mask(e.levels, rank, world),
+                                                     _ptr(self._g), _ptr(self._l), self._hook, None),
+                   "nst_opt_shard_levels")
 
     def step(self, x: torch.Tensor, cw: float, sw: float, tvw: float, want_losses: bool = True):
         """One optimizer.step(closure). Returns (StepInfo, rows[closures, 4*levels+1] or None)."""

@@ -73,6 +73,13 @@ int nst_level_set_targets(nst_ctx* ctx, int level, const float* content, const f
 int nst_closure(nst_ctx* ctx, const float* x, float content_weight, float style_weight,
                 float tv_weight, float* grad, float* losses, void* stream);
 
+/* The same closure restricted to the pyramid levels whose bit is set in level_mask: the level-sharded
+ * form of BASELINE config 4 (rank r owns some levels; loss = sum over levels, so the pixel gradients and
+ * loss rows of the ranks add up: one all-reduce(sum) of `grad` (3*H0*W0 floats) and `losses`).  Rows of
+ * levels not in the mask are zeros; the last element is the sum of the owned level totals. */
+int nst_closure_levels(nst_ctx* ctx, const float* x, float content_weight, float style_weight,
+                       float tv_weight, unsigned level_mask, float* grad, float* losses, void* stream);
+
 /* torch.optim.Adam / torch.optim.LBFGS as constructed at neural_style_transfer.py:134-136,
  * driving nst_closure, including the closure's `lr *= 0.999` (:155-158).  kind: 0 = adam
  * (torch:optim/adam.py:457-546, betas (0.9,0.999), eps 1e-8), 1 = lbfgs
@@ -99,6 +106,15 @@ typedef struct nst_step_info {
  * flow needs the loss), asynchronous on `stream` for Adam when losses_host is NULL. */
 int nst_opt_step(nst_opt* opt, float* x, float content_weight, float style_weight, float tv_weight,
                  float* losses_host, int closures_capacity, nst_step_info* info, void* stream);
+
+/* Level sharding inside the optimiser drivers: every closure the driver evaluates covers only
+ * `level_mask`, then calls hook(user) - which must all-reduce(sum) the `grad` and `losses` DEVICE buffers
+ * given here over the ranks, ordered on the stream passed to nst_opt_step - before the driver reads
+ * them.  The update itself is replicated (deterministic), so no broadcast is needed.  grad: 3*H0*W0
+ * floats, losses: NST_LOSS_ROW*levels+1 floats, both owned by the caller and alive as long as `opt`. */
+typedef void (*nst_reduce_hook)(void* user);
+int nst_opt_shard_levels(nst_opt* opt, unsigned level_mask, float* grad, float* losses, nst_reduce_hook hook,
+                         void* user);
 
 /* ---- standalone pieces of the path, exported for unit parity -------------------------------- */
 

@@ -1,0 +1,299 @@
+"""CPU: the drop-in surface (names, signatures, defaults), the host-side image preparation, the C-ABI
+library (loads, exports every symbol include/nst_hip.h declares, fails loudly when absent) and the
+scheduler logic.  No kernel is launched here."""
+import asyncio
+import ctypes
+import inspect
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------- C ABI
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "nst_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(nst_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from artstyletransfer_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} is declared in include/nst_hip.h but not exported"
+    # the binding table covers the header exactly
+    assert sorted(_lib.SYMBOLS) == names
+    assert _lib.load().nst_version() >= 100
+
+
+def test_no_gpu_is_an_error_not_a_fallback(vgg_weights):
+    import torch
+    from artstyletransfer_amd import _lib
+    from artstyletransfer_amd.engine import StyleEngine
+    lib = _lib.load()
+    n = ctypes.c_int(-1)
+    rc = lib.nst_device_count(ctypes.byref(n))
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert rc != 0 and n.value == 0
+    with pytest.raises(_lib.NstError):
+        StyleEngine(vgg_weights, 0)
+    ctx = ctypes.c_void_p()
+    w = (ctypes.c_void_p * 13)()
+    assert lib.nst_ctx_create(0, w, w, ctypes.byref(ctx)) < 0      # null weights -> NST_E_ARG, no crash
+    assert b"null" in lib.nst_last_error(None)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from artstyletransfer_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", os.path.join(ROOT, "does_not_exist.so"))
+    with pytest.raises(_lib.NstError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "artstyletransfer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"(from|import)\s+oracle|oracle[/.]cpu_ref|cpu_ref", src), f"{f} uses the oracle"
+
+
+# ---------------------------------------------------------------- drop-in surface
+def test_config_surface():
+    import config
+    from artstyletransfer_amd import config as pkg_config
+    assert config.Config is pkg_config.Config
+    assert config.simultaneous_tasks_count == 2
+    c = config.Config()
+    expected = dict(content_weight=1e3, style_weight=4e5, tv_weight=1e2, optimizer="lbfgs", model="vgg19",
+                    init_method="content+noise", levels_num=2, iters_num=500, noise_factor=0.95,
+                    noise_levels=(9, 18, 36, -1, 0), noise_levels_central_amplitude=(0.30, 0.20, 0.10, 0.20, 0.20),
+                    noise_levels_peripheral_amplitude=(0.20, 0.30, 0.40, 0.10, 0.00),
+                    noise_levels_dispersion=(0.20, 0.30, 0.40, 0.60, 0.30))
+    for k, v in expected.items():
+        assert getattr(c, k) == v, k
+    assert config.Config(levels_num=3, iters_num=10).levels_num == 3
+    with pytest.raises(TypeError):
+        config.Config(bogus=1)
+
+
+def test_module_and_signature_surface():
+    import math_utils
+    import neural_nets
+    import neural_style_transfer as nst
+    import task_executor
+    sig = inspect.signature(nst.neural_style_transfer)
+    assert list(sig.parameters)[:14] == [
+        "content_n_style", "content_weight", "style_weight", "tv_weight", "optimizer", "model", "init_method",
+        "iters_num", "levels_num", "noise_factor", "noise_levels", "noise_levels_central_amplitude",
+        "noise_levels_peripheral_amplitude", "noise_levels_dispersion"]
+    assert inspect.isasyncgenfunction(nst.neural_style_transfer)
+    assert inspect.isasyncgenfunction(nst.NeuralStyleTransfer.process)
+    assert list(inspect.signature(nst.NeuralStyleTransfer.__init__).parameters)[1:] == [
+        "device", "model_name", "style_imgs", "optimizer_name"]
+    assert list(inspect.signature(nst.NeuralStyleTransfer.process).parameters)[1:] == [
+        "content_imgs", "init_img", "lr_start", "iters_num", "content_weight", "style_weight", "tv_weight",
+        "init_img_name"]
+    assert inspect.iscoroutinefunction(nst.resize)
+    for name in ("ContentStylePair", "RepresentationBuilder", "LossBuilder", "prepare_img", "unprepare_img",
+                 "gaussian_mask", "make_style_noise", "IMAGENET_MEAN_255"):
+        assert hasattr(nst, name), name
+    assert nst.IMAGENET_MEAN_255 == [123.675, 116.28, 103.53]
+    for name in ("prepare_model", "gram_matrix", "total_variation", "regularization"):
+        assert hasattr(math_utils, name), name
+    net = neural_nets.Vgg19.__new__(neural_nets.Vgg19)
+    assert list(inspect.signature(neural_nets.Vgg19.__init__).parameters)[1:] == [
+        "requires_grad", "show_progress", "use_relu"]
+    for name in ("Task", "Executor"):
+        assert hasattr(task_executor, name)
+    for m in ("add_task", "get_progress", "progress", "task_ids", "set_progress", "run"):
+        assert hasattr(task_executor.Executor, m), m
+    with pytest.raises(ValueError, match="not supported"):
+        math_utils.prepare_model("resnet", "cpu")
+    del net
+
+
+def test_vgg19_attributes(monkeypatch):
+    import warnings
+    from artstyletransfer_amd import neural_nets
+    monkeypatch.delenv("NST_VGG19_WEIGHTS", raising=False)
+    monkeypatch.setattr(neural_nets, "_weights_cache", None)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        net = neural_nets.Vgg19()
+        assert any("synthetic" in str(x.message) for x in w)
+    assert net.layer_names == ["relu1_1", "relu2_1", "relu3_1", "relu4_1", "conv4_2", "relu5_1"]
+    assert net.content_feature_maps_index == 4 and net.style_feature_maps_indices == [0, 1, 2, 3, 5]
+    assert len(list(net.parameters())) == 26
+    assert sum(p.numel() for p in net.parameters()) == 12944960
+    assert net.to("cpu").eval() is net
+
+
+# ---------------------------------------------------------------- host image preparation
+def test_level_size_rule():
+    from artstyletransfer_amd import host_image as hi
+    assert hi.level_size(2875, 4312, 0) == (256, 383)        # 4312x2875 -> 383x256
+    assert hi.level_size(2875, 4312, 2) == (1024, 1532)
+    assert hi.level_size(391, 470, 0) == (256, 307)
+    assert hi.level_size(500, 500, 1) == (512, 512)
+    assert hi.level_size(1024, 1536, 2) == (1024, 1536)
+    assert hi.level_size(300, 200, 0) == (384, 256)
+
+
+def test_bicubic_resize_properties():
+    from artstyletransfer_amd import host_image as hi
+    img = np.random.RandomState(0).rand(20, 30, 3).astype(np.float32)
+    same = hi.bicubic_resize(img, 20, 30)
+    np.testing.assert_allclose(same, img, atol=1e-6)          # identity scale: taps collapse onto the pixel
+    const = np.full((8, 12, 3), 0.25, dtype=np.float32)
+    np.testing.assert_allclose(hi.bicubic_resize(const, 32, 48), 0.25, atol=1e-6)
+    up = hi.bicubic_resize(img, 40, 60)
+    assert up.shape == (40, 60, 3) and up.dtype == np.float32
+    # exact 1/2 down-sample = the fixed 4-tap filter [-3, 19, 19, -3] / 32, interior pixel
+    dn = hi.bicubic_resize(img, 10, 15)
+    w = np.array([-3, 19, 19, -3], dtype=np.float64) / 32
+    ref = sum(w[a] * w[b] * img[2 * 4 - 1 + a, 2 * 5 - 1 + b, 1] for a in range(4) for b in range(4))
+    assert dn[4, 5, 1] == pytest.approx(ref, rel=1e-5)
+
+
+def test_gaussian_kernel_and_mask():
+    from artstyletransfer_amd import host_image as hi
+    k = hi.gaussian_kernel(7, 1.5)
+    assert k.sum() == pytest.approx(1.0) and np.allclose(k, k[::-1]) and k.argmax() == 3
+    m = hi.gaussian_mask((40, 60, 3), 0.3, 0.2, 0.2)
+    assert m.shape == (40, 60, 3) and m.dtype == np.float64
+    assert m[20, 30, 0] == pytest.approx(0.3)                # centre = central amplitude
+    assert abs(m[0, 0, 0] - 0.2) < 1e-2                      # far corner -> peripheral amplitude
+    assert np.array_equal(m[..., 0], m[..., 2])
+
+
+def test_sobel_and_blur():
+    from artstyletransfer_amd import host_image as hi
+    ramp = np.tile(np.arange(12, dtype=np.float32), (9, 1))[..., None].repeat(3, axis=2)
+    gx = hi.sobel5(ramp, 1, 0)
+    # unit ramp: sum(deriv taps * offset) * sum(smooth taps) = (2 + 2 + 0 + 2 + 2) * 16
+    assert gx[4, 5, 0] == pytest.approx(128.0)
+    assert np.abs(hi.sobel5(ramp, 0, 1)[2:-2]).max() == pytest.approx(0.0)
+    img = np.random.RandomState(1).rand(16, 16, 3)
+    np.testing.assert_allclose(hi.gaussian_blur(img, 101, 0.2), img, atol=1e-4)   # sigma 0.2 ~ identity
+
+
+def test_noise_init_reproducible_and_shaped():
+    from artstyletransfer_amd import config, host_image as hi, synthetic
+    cfg = config.Config()
+    content = synthetic.image(64, 96, 1)
+    style = synthetic.image(64, 96, 2)
+    ct, st = hi.resize_to_level(content, 0), hi.resize_to_level(style, 0)
+    assert ct.shape == (256, 384, 3)
+
+    def make(method):
+        np.random.seed(0)
+        return hi.initial_image(method, content, style, ct, st, 0, cfg.noise_factor, cfg.noise_levels,
+                                cfg.noise_levels_central_amplitude, cfg.noise_levels_peripheral_amplitude,
+                                cfg.noise_levels_dispersion)
+    a, tag = make("content+noise")
+    b, _ = make("content+noise")
+    assert tag == "content" and a.dtype == np.float32 and a.shape == ct.shape
+    np.testing.assert_array_equal(a, b)
+    r, tag = make("random")
+    assert tag == "random" and r.shape == ct.shape
+    s, tag = make("anything else")
+    assert tag == "style"
+    np.testing.assert_array_equal(s, st)
+    # make_style_noise permutes the resized style pixels as whole RGB rows
+    np.random.seed(3)
+    low = hi.make_style_noise(st, (9, 13, 3))
+    src = hi.bicubic_resize(st, 9, 13).reshape(-1, 3)
+    assert sorted(map(tuple, low.reshape(-1, 3))) == sorted(map(tuple, src))
+
+
+# ---------------------------------------------------------------- scheduler
+def test_executor_runs_jobs_on_separate_gpus(monkeypatch):
+    from artstyletransfer_amd import config, task_executor as te
+    placed = []
+
+    async def fake_nst(pair, *args, device=None):
+        placed.append(device.index)
+        for k in range(3):
+            await asyncio.sleep(0.01)
+            yield (k + 1) / 3 * 100.0, np.full((4, 4, 3), k, dtype=np.float32)
+
+    monkeypatch.setattr(te, "neural_style_transfer", fake_nst)
+    reports = []
+
+    async def report(task_id, result):
+        reports.append((task_id, result[0]))
+
+    async def main():
+        ex = te.Executor(config.Config(iters_num=3), report_progress=report, gpu_slots=te.GpuSlots(per_gpu=1, n_gpus=4))
+        pair = te.ContentStylePair(("c", None), ("s", None))
+        for i in range(6):
+            await ex.add_task(f"t{i}", pair)
+        assert await ex.get_progress("t0") == (-1, None) or (await ex.get_progress("t0"))[0] >= -1
+        assert sorted(await ex.task_ids()) == [f"t{i}" for i in range(6)]
+        await ex.run(forever=False)          # returns at once, like the reference
+        await ex.wait_all()
+        return ex
+
+    ex = asyncio.run(main())
+    assert sorted(placed[:4]) == [0, 1, 2, 3]        # the first four jobs each got their own GPU
+    assert len(placed) == 6
+    assert len(reports) == 18
+
+    async def final():
+        p, img = await ex.get_progress("t5")
+        assert p == pytest.approx(100.0) and img.shape == (4, 4, 3)
+        img[:] = -1                                   # a copy was handed out
+        assert (await ex.get_progress("t5"))[1].max() == 2
+    asyncio.run(final())
+
+
+def test_job_failure_releases_its_gpu(monkeypatch):
+    from artstyletransfer_amd import config, task_executor as te
+
+    async def failing(pair, *args, device=None):
+        raise RuntimeError("boom")
+        yield  # pragma: no cover
+
+    monkeypatch.setattr(te, "neural_style_transfer", failing)
+
+    async def main():
+        slots = te.GpuSlots(per_gpu=1, n_gpus=1)
+        ex = te.Executor(config.Config(), gpu_slots=slots)
+        job = await ex.add_task("bad", te.ContentStylePair(("c", None), ("s", None)))
+        with pytest.raises(RuntimeError, match="boom"):
+            await job
+        assert await slots.acquire() == 0             # the token came back
+
+    asyncio.run(main())
+
+
+def test_process_rejects_unknown_optimizer_and_model():
+    import neural_style_transfer as nst
+
+    async def run(model, optimizer):
+        n = nst.NeuralStyleTransfer("cpu", model, [np.zeros((32, 32, 3), np.float32)], optimizer)
+        async for _ in n.process([np.zeros((32, 32, 3), np.float32)], np.zeros((32, 32, 3), np.float32), 10.0, 1,
+                                 1.0, 1.0, 1.0, "x"):
+            pass
+
+    with pytest.raises(ValueError, match="not supported"):
+        asyncio.run(run("alexnet", "adam"))
+    with pytest.raises(RuntimeError, match="Unknown optimizer"):
+        asyncio.run(run("vgg19", "sgd"))
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="GPU"):
+            asyncio.run(run("vgg19", "adam"))
