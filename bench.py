@@ -86,6 +86,32 @@ def cpu_baseline(job_host, cfg, closures: int):
             "seconds": round(total, 2)}
 
 
+def one_stream_pass(args, cfg, closures: int = 6):
+    """Per-kernel durations with every level serialised on one stream (a second engine on the same workload)."""
+    os.environ["NST_SINGLE_STREAM"] = "1"
+    try:
+        eng, x, _, _ = build_job(args.levels, 0, torch.cuda.current_device())
+    finally:
+        del os.environ["NST_SINGLE_STREAM"]
+    cw, sw, tvw = cfg.content_weight, cfg.style_weight, cfg.tv_weight
+    for _ in range(2):
+        eng.closure(x, cw, sw, tvw)
+    torch.cuda.synchronize()
+    eng.set_timing(2)
+    eng.timing_totals(0, reset=True)
+    for _ in range(closures):
+        eng.closure(x, cw, sw, tvw)
+    torch.cuda.synchronize()
+    ms, n, fl = eng.timing_totals(0)
+    cms, cn, _ = eng.timing_totals(-1)
+    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    res = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+           "frac": ach / FP32_MFMA_PEAK_TFLOPS, "launches": n, "avg_launch_ms": ms / max(n, 1),
+           "closure_ms": cms / max(cn, 1), "conv3x3_ms_per_closure": ms / max(cn, 1)}
+    eng.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -205,6 +231,14 @@ def main():
             out["kernel_ms_per_closure"] = {
                 "closure": cms / max(cn, 1), "conv3x3_mfma": ms / max(cn, 1), "gram_mfma": gms / max(cn, 1),
                 "conv1_1": c1ms / max(cn, 1), "streaming": oms / max(cn, 1)}
+            if world == 1 and not os.environ.get("NST_SINGLE_STREAM"):
+                # Under the default schedule the pyramid levels run on separate HIP streams, so the launch durations
+                # above are taken while kernels of other levels share the CUs (their sum exceeds the closure time).
+                # The same closures re-run on ONE stream give each kernel's duration with the chip to itself.
+                out["roofline"]["note"] = ("launch durations measured while kernels of the other pyramid levels run "
+                                           "concurrently on their own streams; roofline_one_stream = same closures "
+                                           "serialised on one stream")
+                out["roofline_one_stream"] = one_stream_pass(args, cfg)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(job_host, cfg, args.cpu_closures)
         print(json.dumps(out), flush=True)
