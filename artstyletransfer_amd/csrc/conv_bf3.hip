@@ -1,0 +1,323 @@
+// conv_bf3.hip - the 3x3 convolutions (forward and input gradient) on the gfx950 bf16 matrix pipe at
+// fp32-level accuracy.  Every fp32 operand is cut into three bf16 pieces that add up to it EXACTLY
+// (8 + 8 + 8 = 24 significand bits; each residual subtraction is exact in fp32):
+//       a = a0 + a1 + a2,   b = b0 + b1 + b2,      |a_i| <= 2^-8i |a|
+// and the product is taken as the six terms with i + j <= 2:
+//       a*b ~= a0 b0 + (a0 b1 + a1 b0) + (a1 b1 + a0 b2 + a2 b0)        dropped: <= 3 * 2^-24 |a b|
+// Each bf16 x bf16 product is exact in fp32 and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the
+// result carries the same order of error as an fp32 FMA chain, while 6 bf16 MFMAs cost 6 x 32 = 192 cycles
+// per 32x32x16 block against 8 x 64 = 512 for v_mfma_f32_32x32x2_f32: 2.67x the fp32-MFMA ceiling.
+//
+// Same implicit-GEMM structure as conv_mfma.hip (halo patch of a 32-channel chunk staged once per 9 taps,
+// per-tap weight slice double buffered, issue-early / write-late), but one 512-thread workgroup per CU:
+// 16x16 (or 32x16) pixels x 128 (64) output channels, 8 waves of 64x64.  Activations stay fp32 in HBM and
+// are cut while being staged into LDS (8 VALU ops per element, once per 9 taps); the frozen weights are cut
+// once on the host.  LDS rows hold the three pieces of 32 channels back to back (3 x 64 B) + 16 B pad = 208 B
+// = 13 x 16 B: 16 consecutive rows start on 16 distinct 16-B slots -> conflict-free ds_read_b128 fragments.
+#include <hip/hip_runtime.h>
+
+#include "nst_kernels.h"
+
+namespace nst {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int KC = 32;            // channels per chunk
+constexpr int ROWB = 208;         // LDS row bytes: 3 pieces x 64 B + 16 B pad
+constexpr int WROWB = 192;        // global weight row bytes per (tap, cout, chunk): 3 pieces x 32 bf16
+
+template <int TH, int BN>
+struct BfCfg {
+    static constexpr int TW = 16;
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int WM = TH / 4;            // waves along pixels (4 rows x 16 cols each)
+    static constexpr int WN = BN / 64;
+    static constexpr int NT = 64 * WM * WN;      // 512
+    static constexpr int A_UNITS = PH * PW * (KC / 4);        // float4 units of the fp32 patch
+    static constexpr int A_PER_T = (A_UNITS + NT - 1) / NT;
+    static constexpr int B_UNITS = BN * (WROWB / 16);         // 16-byte units of the weight slice
+    static constexpr int B_PER_T = (B_UNITS + NT - 1) / NT;
+    static constexpr int A_BYTES = PH * PW * ROWB;
+    static constexpr int B_BYTES = BN * ROWB;
+    static constexpr int LDS_BYTES = A_BYTES + 2 * B_BYTES;
+    static_assert(NT == 512, "eight waves per workgroup");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// a = h + m + l exactly, each piece a bf16 held in the TOP half of a 32-bit word
+__device__ __forceinline__ void cut3(float a, unsigned& h, unsigned& m, unsigned& l) {
+    h = __float_as_uint(a) & 0xFFFF0000u;
+    const float r1 = a - __uint_as_float(h);
+    m = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(m);
+    l = __float_as_uint(r2);                      // <= 8 significant bits left: exact in bf16
+}
+// two top-half bf16 -> one packed dword {lo16 = first, hi16 = second}
+__device__ __forceinline__ unsigned pack2(unsigned first, unsigned second) {
+    return __builtin_amdgcn_perm(second, first, 0x07060302u);
+}
+
+}  // namespace
+
+template <int TH, int BN>
+__global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
+    using C = BfCfg<TH, BN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ldsA = smem;
+    unsigned char* ldsB = smem + C::A_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % C::WM;
+    const int wn = wave / C::WM;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int n_ct = p.Cout / BN;
+    const int bid = blockIdx.x;
+    const int ct = bid % n_ct;
+    const int sp = bid / n_ct;
+    const int ty = sp / p.tiles_x;
+    const int tx = sp - ty * p.tiles_x;
+    const int y0 = ty * TH;
+    const int x0 = tx * C::TW;
+    const int n0 = ct * BN;
+
+    const int nchunks_all = p.Cin / KC;
+    const int cps = nchunks_all / p.ksplit;
+    const int c_begin = blockIdx.y * cps;
+    const int c_end = c_begin + cps;
+
+    f32x4 ra[C::A_PER_T];
+    u32x4 rb[C::B_PER_T];
+
+    auto load_a = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < C::A_PER_T; ++i) {
+            const int u = tid + i * C::NT;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (u < C::A_UNITS) {
+                const int pix = u >> 3;
+                const int q = u & 7;
+                const int pr = pix / C::PW;
+                const int pc = pix - pr * C::PW;
+                const int gy = y0 - 1 + pr;
+                const int gx = x0 - 1 + pc;
+                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+                    v = *reinterpret_cast<const f32x4*>(p.in + ((size_t)gy * p.W + gx) * p.Cin + chunk * KC + q * 4);
+            }
+            ra[i] = v;
+        }
+    };
+    // cut the staged fp32 values into their three bf16 pieces and write 8 bytes per piece
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < C::A_PER_T; ++i) {
+            const int u = tid + i * C::NT;
+            if (u < C::A_UNITS) {
+                const int pix = u >> 3;
+                const int q = u & 7;
+                unsigned h[4], m[4], l[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) cut3(ra[i][k], h[k], m[k], l[k]);
+                unsigned char* row = ldsA + pix * ROWB + q * 8;
+                *reinterpret_cast<u32x2*>(row) = u32x2{pack2(h[0], h[1]), pack2(h[2], h[3])};
+                *reinterpret_cast<u32x2*>(row + 64) = u32x2{pack2(m[0], m[1]), pack2(m[2], m[3])};
+                *reinterpret_cast<u32x2*>(row + 128) = u32x2{pack2(l[0], l[1]), pack2(l[2], l[3])};
+            }
+        }
+    };
+    // weights: [tap][Cout][chunk][piece][32] bf16, i.e. 192 contiguous bytes per (tap, cout, chunk)
+    auto load_b = [&](int chunk, int tap) {
+        const unsigned char* base = reinterpret_cast<const unsigned char*>(p.wt_bf) +
+                                    (((size_t)tap * p.Cout + n0) * nchunks_all + chunk) * WROWB;
+#pragma unroll
+        for (int i = 0; i < C::B_PER_T; ++i) {
+            const int u = tid + i * C::NT;
+            if (u < C::B_UNITS) {
+                const int n = u / 12;
+                const int q = u - n * 12;
+                rb[i] = *reinterpret_cast<const u32x4*>(base + (size_t)n * nchunks_all * WROWB + q * 16);
+            }
+        }
+    };
+    auto store_b = [&](int buf) {
+        unsigned char* dst = ldsB + buf * C::B_BYTES;
+#pragma unroll
+        for (int i = 0; i < C::B_PER_T; ++i) {
+            const int u = tid + i * C::NT;
+            if (u < C::B_UNITS) {
+                const int n = u / 12;
+                const int q = u - n * 12;
+                *reinterpret_cast<u32x4*>(dst + n * ROWB + q * 16) = rb[i];
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // fragment addresses: lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8h + j], B[k = 8h + j][col r]
+    const int prow = wm * 4 + (l31 >> 4);
+    const int pcol = l31 & 15;
+    const int a_off0 = ((prow + 0) * C::PW + pcol) * ROWB + half * 16;
+    const int a_off1 = ((prow + 2) * C::PW + pcol) * ROWB + half * 16;
+    const int b_off0 = (wn * 64 + l31) * ROWB + half * 16;
+    const int b_off1 = (wn * 64 + 32 + l31) * ROWB + half * 16;
+
+    load_a(c_begin);
+    load_b(c_begin, 0);
+    int cur = 0;
+    for (int c = c_begin; c < c_end; ++c) {
+        if (c > c_begin) __syncthreads();
+        store_a();
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            store_b(cur);
+            __syncthreads();
+            if (t + 1 < 9) {
+                load_b(c, t + 1);
+            } else if (c + 1 < c_end) {
+                load_b(c + 1, 0);
+                load_a(c + 1);
+            }
+            const int tap_off = ((t / 3) * C::PW + (t % 3)) * ROWB;
+            const unsigned char* bsrc = ldsB + cur * C::B_BYTES;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    fa[0][s] = *reinterpret_cast<const bf16x8*>(ldsA + a_off0 + tap_off + s * 64 + ks * 32);
+                    fa[1][s] = *reinterpret_cast<const bf16x8*>(ldsA + a_off1 + tap_off + s * 64 + ks * 32);
+                    fb[0][s] = *reinterpret_cast<const bf16x8*>(bsrc + b_off0 + s * 64 + ks * 32);
+                    fb[1][s] = *reinterpret_cast<const bf16x8*>(bsrc + b_off1 + s * 64 + ks * 32);
+                }
+                // smallest terms first; the six products of one (mt, nt) form one accumulation chain
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        f32x16 v = acc[mt][nt];
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][2], fb[nt][0], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][2], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[nt][1], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[nt][0], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][1], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][0], v, 0, 0, 0);
+                        acc[mt][nt] = v;
+                    }
+            }
+            cur ^= 1;
+        }
+    }
+
+    // epilogue: D[m][n]: n = lane&31, m = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (p.ksplit > 1) {
+        float* dst = p.partial + (size_t)blockIdx.y * p.H * p.W * p.Cout;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int co = n0 + wn * 64 + nt * 32 + l31;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int y = y0 + wm * 4 + mt * 2 + (m >> 4);
+                    const int x = x0 + (m & 15);
+                    if (y < p.H && x < p.W) dst[((size_t)y * p.W + x) * p.Cout + co] = acc[mt][nt][r];
+                }
+        }
+        return;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int co = n0 + wn * 64 + nt * 32 + l31;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int y = y0 + wm * 4 + mt * 2 + (m >> 4);
+                const int x = x0 + (m & 15);
+                if (y < p.H && x < p.W) {
+                    const size_t idx = ((size_t)y * p.W + x) * p.Cout + co;
+                    float v = acc[mt][nt][r] + bv;
+                    if (p.addend) v += p.addend[idx];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.mask) v = (p.mask[idx] > 0.f) ? v : 0.f;
+                    p.out[idx] = v;
+                }
+            }
+    }
+}
+
+hipError_t conv_bf3_init_device() {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<16, 128>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, BfCfg<16, 128>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<32, 64>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, BfCfg<32, 64>::LDS_BYTES);
+}
+
+// one workgroup per CU here, so a layer needs >= ~200 tiles before split-K stops paying
+int conv_bf3_ksplit(int H, int W, int Cin, int Cout) {
+    const bool wide = (Cout % 128 == 0);
+    const int th = wide ? 16 : 32, bn = wide ? 128 : 64;
+    const long blocks = (long)((H + th - 1) / th) * ((W + 15) / 16) * (Cout / bn);
+    const int nchunks = Cin / 32;
+    if (blocks >= 192 || nchunks < 2) return 1;
+    double best = 1e30;
+    for (int S = 1; S <= nchunks && S <= 16; S *= 2) {
+        if (nchunks % S) continue;
+        const double c = (double)((blocks * S + 255) / 256) * (nchunks / S);
+        if (c < best) best = c;
+    }
+    for (int S = 1; S <= nchunks && S <= 16; S *= 2) {
+        if (nchunks % S) continue;
+        const double c = (double)((blocks * S + 255) / 256) * (nchunks / S);
+        if (c <= best * 1.05) return S;
+    }
+    return 1;
+}
+
+hipError_t launch_conv_bf3(const ConvParams& p0, hipStream_t stream) {
+    if (p0.Cin % 32 != 0 || p0.Cout % 64 != 0 || !p0.wt_bf) return hipErrorInvalidValue;
+    ConvParams p = p0;
+    p.ksplit = 1;
+    if (p.partial) {
+        const int S = conv_bf3_ksplit(p.H, p.W, p.Cin, p.Cout);
+        if (S > 1 && (size_t)S * p.H * p.W * p.Cout <= p.partial_floats) p.ksplit = S;
+    }
+    const bool wide = (p.Cout % 128 == 0);
+    p.tiles_x = (p.W + 15) / 16;
+    if (wide) {
+        p.tiles_y = (p.H + 15) / 16;
+        const int blocks = p.tiles_x * p.tiles_y * (p.Cout / 128);
+        constexpr int lds = BfCfg<16, 128>::LDS_BYTES;
+        hipLaunchKernelGGL((conv_bf3_kernel<16, 128>), dim3(blocks, p.ksplit), dim3(512), lds, stream, p);
+    } else {
+        p.tiles_y = (p.H + 31) / 32;
+        const int blocks = p.tiles_x * p.tiles_y * (p.Cout / 64);
+        constexpr int lds = BfCfg<32, 64>::LDS_BYTES;
+        hipLaunchKernelGGL((conv_bf3_kernel<32, 64>), dim3(blocks, p.ksplit), dim3(512), lds, stream, p);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || p.ksplit == 1) return e;
+    return launch_conv_splitk_finish(p, stream);
+}
+
+}  // namespace nst

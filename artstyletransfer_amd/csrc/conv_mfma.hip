@@ -268,6 +268,14 @@ __global__ __launch_bounds__(256) void conv_splitk_finish_kernel(ConvParams p) {
     }
 }
 
+hipError_t launch_conv_splitk_finish(const ConvParams& p, hipStream_t stream) {
+    const size_t n4 = (size_t)p.H * p.W * p.Cout / 4;
+    size_t fb = (n4 + 255) / 256;
+    if (fb > 2048) fb = 2048;
+    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((int)fb), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
 // Split the channel chunks over S blocks when the (spatial x channel) tiles alone cannot fill the chip.
 // cost(S) = waves of blocks over the 256 CUs x chunks per block; smallest S within 5 % of the best.
 int conv_ksplit(int H, int W, int Cin, int Cout) {
@@ -301,11 +309,7 @@ static hipError_t launch_cfg(const ConvParams& p0, hipStream_t stream) {
     hipLaunchKernelGGL((conv_mfma_kernel<TH, BN, KC, TAPS>), dim3(blocks, p.ksplit), dim3(C::NT), C::LDS_BYTES, stream, p);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.ksplit == 1) return e;
-    const size_t n4 = (size_t)p.H * p.W * p.Cout / 4;
-    size_t fb = (n4 + 255) / 256;
-    if (fb > 2048) fb = 2048;
-    hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((int)fb), dim3(256), 0, stream, p);
-    return hipGetLastError();
+    return launch_conv_splitk_finish(p, stream);
 }
 
 template <int TH, int BN, int KC, int TAPS>

@@ -5,7 +5,9 @@
 // Host-side control only; every FLOP and byte of the path is in the .hip kernels.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -73,6 +75,9 @@ struct nst_ctx {
     std::string err;
     float* wf[NL] = {};
     float* wd[NL] = {};
+    void* wf_bf[NL] = {};       // the same weights cut into 3 bf16 pieces (conv_bf3.hip layout)
+    void* wd_bf[NL] = {};
+    int conv_bf3 = 1;           // 1: 3x3 convs on the bf16 pipe with 3-piece operands; 0: fp32 MFMA
     float* bias[NL] = {};
     float* w11k = nullptr;      // [28][64]
     float* w11d = nullptr;      // [9][64][4]
@@ -147,8 +152,10 @@ int alloc_acts(nst_ctx* ctx, ActSet& a, int h, int w) {
     size_t need = 0;
     for (int l = 1; l < NL; ++l) {
         const size_t px = (size_t)a.h[l] * a.w[l];
-        const size_t fwd = (size_t)conv_ksplit(a.h[l], a.w[l], kCin[l], kCout[l]) * px * kCout[l];
-        const size_t bwd = (size_t)conv_ksplit(a.h[l], a.w[l], kCout[l], kCin[l]) * px * kCin[l];
+        const int sf = std::max(conv_ksplit(a.h[l], a.w[l], kCin[l], kCout[l]), conv_bf3_ksplit(a.h[l], a.w[l], kCin[l], kCout[l]));
+        const int sb = std::max(conv_ksplit(a.h[l], a.w[l], kCout[l], kCin[l]), conv_bf3_ksplit(a.h[l], a.w[l], kCout[l], kCin[l]));
+        const size_t fwd = (size_t)sf * px * kCout[l];
+        const size_t bwd = (size_t)sb * px * kCin[l];
         if (fwd > px * kCout[l] && fwd > need) need = fwd;
         if (bwd > px * kCin[l] && bwd > need) need = bwd;
     }
@@ -165,6 +172,33 @@ void free_acts(nst_ctx* ctx, ActSet& a) {
     dev_free(a.splitk); a.splitk = nullptr; a.splitk_floats = 0;
     if (ctx->bytes >= a.bytes) ctx->bytes -= a.bytes;
     a.bytes = 0;
+}
+
+// fp32 -> three bf16 pieces that sum to it exactly (same cut as conv_bf3.hip::cut3)
+void cut3_host(float a, uint16_t& h, uint16_t& m, uint16_t& l) {
+    uint32_t u; std::memcpy(&u, &a, 4);
+    const uint32_t uh = u & 0xFFFF0000u;
+    float fh; std::memcpy(&fh, &uh, 4);
+    const float r1 = a - fh;
+    uint32_t u1; std::memcpy(&u1, &r1, 4);
+    const uint32_t um = u1 & 0xFFFF0000u;
+    float fm; std::memcpy(&fm, &um, 4);
+    const float r2 = r1 - fm;
+    uint32_t u2; std::memcpy(&u2, &r2, 4);
+    h = (uint16_t)(uh >> 16); m = (uint16_t)(um >> 16); l = (uint16_t)(u2 >> 16);
+}
+// w: [taps][rows][K] fp32  ->  out: [taps][rows][K/32][3][32] bf16
+void make_bf3(const float* w, int taps, int rows, int K, std::vector<uint16_t>& out) {
+    const int nch = K / 32;
+    out.assign((size_t)taps * rows * nch * 96, 0);
+    for (int t = 0; t < taps; ++t)
+        for (int r = 0; r < rows; ++r)
+            for (int k = 0; k < K; ++k) {
+                uint16_t h, m, l;
+                cut3_host(w[((size_t)t * rows + r) * K + k], h, m, l);
+                const size_t base = (((size_t)t * rows + r) * nch + k / 32) * 96 + (k % 32);
+                out[base] = h; out[base + 32] = m; out[base + 64] = l;
+            }
 }
 
 int pool_index_after(int l) {
@@ -204,10 +238,10 @@ int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s
         ConvParams p{};
         p.in = in; p.wt = ctx->wf[l]; p.bias = ctx->bias[l]; p.addend = nullptr; p.mask = nullptr; p.out = a.act[l];
         p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCin[l]; p.Cout = kCout[l]; p.relu = 1;
-        p.partial = a.splitk; p.partial_floats = a.splitk_floats;
+        p.partial = a.splitk; p.partial_floats = a.splitk_floats; p.wt_bf = ctx->wf_bf[l];
         {
             Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, l);
-            HIPCHK(ctx, launch_conv_mfma(p, 9, s));
+            HIPCHK(ctx, ctx->conv_bf3 ? launch_conv_bf3(p, s) : launch_conv_mfma(p, 9, s));
         }
         const int pa = pool_index_after(l);
         if (pa >= 0 && l < last_layer) {
@@ -257,11 +291,11 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
         ConvParams p{};
         p.in = cur; p.wt = ctx->wd[l]; p.out = oth;
         p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCout[l]; p.Cout = kCin[l];
-        p.partial = a.splitk; p.partial_floats = a.splitk_floats;
+        p.partial = a.splitk; p.partial_floats = a.splitk_floats; p.wt_bf = ctx->wd_bf[l];
         if (pk >= 0) {
             {
                 Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, -l);
-                HIPCHK(ctx, launch_conv_mfma(p, 9, s));
+                HIPCHK(ctx, ctx->conv_bf3 ? launch_conv_bf3(p, s) : launch_conv_mfma(p, 9, s));
             }
             // oth = g(pool[pk]); un-pool through act[l-1] with its ReLU mask -> cur
             Timer t(ctx, s, K_OTHER, 0);
@@ -287,7 +321,7 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
             p.mask = a.act[m];
             {
                 Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, -l);
-                HIPCHK(ctx, launch_conv_mfma(p, 9, s));
+                HIPCHK(ctx, ctx->conv_bf3 ? launch_conv_bf3(p, s) : launch_conv_mfma(p, 9, s));
             }
             float* tmp = cur; cur = oth; oth = tmp;
         }
@@ -391,12 +425,16 @@ int nst_ctx_create(int device, const float* const* weights, const float* const* 
     auto bail = [&](int code) { g_err = ctx->err; nst_ctx_destroy(ctx); return code; };
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(NST_E_HIP); }
     hipError_t e = conv_mfma_init_device();
+    if (e == hipSuccess) e = conv_bf3_init_device();
     if (e == hipSuccess) e = gram_init_device();
+    const char* cm = getenv("NST_CONV");
+    if (cm && std::strcmp(cm, "f32") == 0) ctx->conv_bf3 = 0;
     if (e != hipSuccess) { ctx->err = std::string("kernel attribute setup: ") + hipGetErrorString(e); return bail(NST_E_HIP); }
     const char* ss = getenv("NST_SINGLE_STREAM");
     ctx->single_stream = ss && ss[0] == '1';
 
     std::vector<float> tmp;
+    std::vector<uint16_t> tmp16;
     for (int l = 0; l < NL; ++l) {
         const int ci = kCin[l], co = kCout[l];
         const float* W = weights[l];   // [co][ci][3][3]
@@ -427,6 +465,9 @@ int nst_ctx_create(int device, const float* const* weights, const float* const* 
                 for (int c = 0; c < ci; ++c) tmp[((size_t)t * co + o) * ci + c] = W[((size_t)o * ci + c) * 9 + t];
         if (dev_alloc_t(ctx, &ctx->wf[l], n) != NST_OK) return bail(NST_E_NOMEM);
         if (hipMemcpy(ctx->wf[l], tmp.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+        make_bf3(tmp.data(), 9, co, ci, tmp16);
+        if (dev_alloc(ctx, &ctx->wf_bf[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
+        if (hipMemcpy(ctx->wf_bf[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
         // input gradient: a conv with "Cout" = ci and "Cin" = co: wd[tap'][ci][co] = W[co][ci][2-ky'][2-kx']
         for (int t = 0; t < 9; ++t) {
             const int ky = 2 - t / 3, kx = 2 - t % 3;
@@ -435,6 +476,9 @@ int nst_ctx_create(int device, const float* const* weights, const float* const* 
         }
         if (dev_alloc_t(ctx, &ctx->wd[l], n) != NST_OK) return bail(NST_E_NOMEM);
         if (hipMemcpy(ctx->wd[l], tmp.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+        make_bf3(tmp.data(), 9, ci, co, tmp16);
+        if (dev_alloc(ctx, &ctx->wd_bf[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
+        if (hipMemcpy(ctx->wd_bf[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
     }
     if (hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
@@ -450,7 +494,7 @@ void nst_ctx_destroy(nst_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < NST_MAX_LEVELS; ++i) free_level(ctx, ctx->lv[i]);
-    for (int l = 0; l < NL; ++l) { dev_free(ctx->wf[l]); dev_free(ctx->wd[l]); dev_free(ctx->bias[l]); }
+    for (int l = 0; l < NL; ++l) { dev_free(ctx->wf[l]); dev_free(ctx->wd[l]); dev_free(ctx->bias[l]); dev_free(ctx->wf_bf[l]); dev_free(ctx->wd_bf[l]); }
     dev_free(ctx->w11k); dev_free(ctx->w11d);
     if (ctx->fork) (void)hipEventDestroy(ctx->fork);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);

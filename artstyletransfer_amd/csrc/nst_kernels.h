@@ -11,6 +11,7 @@ namespace nst {
 struct ConvParams {
     const float* in;      // [H][W][Cin]
     const float* wt;      // [TAPS][Cout][Cin]
+    const void* wt_bf;    // conv_bf3 only: [9][Cout][Cin/32][3 pieces][32] bf16 (see conv_bf3.hip)
     const float* bias;    // [Cout] or nullptr
     const float* addend;  // [H][W][Cout] or nullptr (may alias out)
     const float* mask;    // [H][W][Cout] or nullptr: out = mask > 0 ? v : 0
@@ -28,6 +29,13 @@ hipError_t conv_mfma_init_device();
 hipError_t launch_conv_mfma(const ConvParams& p, int taps, hipStream_t stream);
 // number of channel-chunk splits launch_conv_mfma uses for a 3x3 layer of this shape (1 = none)
 int conv_ksplit(int H, int W, int Cin, int Cout);
+
+hipError_t launch_conv_splitk_finish(const ConvParams& p, hipStream_t stream);
+
+// conv_bf3.hip: the same 3x3 convolution on the bf16 matrix pipe with 3-piece operands (fp32-level accuracy)
+hipError_t conv_bf3_init_device();
+hipError_t launch_conv_bf3(const ConvParams& p, hipStream_t stream);
+int conv_bf3_ksplit(int H, int W, int Cin, int Cout);
 
 // conv_first.hip: conv1_1 (3 -> 64) forward from the planar image, and its input gradient
 // wk: [28][64] (k = c*9 + ky*3 + kx, row 27 zero); bias [64]; out NHWC 64, ReLU applied.
