@@ -43,7 +43,10 @@ struct BfCfg {
     static constexpr int A_PER_T = (A_UNITS + NT - 1) / NT;
     static constexpr int B_UNITS = BN * (WROWB / 16);         // 16-byte units of the weight slice
     static constexpr int B_PER_T = (B_UNITS + NT - 1) / NT;
-    static constexpr int A_BYTES = PH * PW * ROWB;
+    // patch-row pitch rounded up to a multiple of 256 B: the two patch rows a 32-pixel MFMA tile spans then
+    // start on the same 16-B slot, which makes every ds_read_b128 lane group hit 16 distinct slots
+    static constexpr int PROWB = ((PW * ROWB + 255) / 256) * 256;
+    static constexpr int A_BYTES = PH * PROWB;
     static constexpr int B_BYTES = BN * ROWB;
     static constexpr int LDS_BYTES = A_BYTES + 2 * B_BYTES;
     static_assert(NT == 512, "eight waves per workgroup");
@@ -98,36 +101,54 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
     f32x4 ra[C::A_PER_T];
     u32x4 rb[C::B_PER_T];
 
-    auto load_a = [&](int chunk) {
+    // buffer loads: 32-bit per-lane offsets that do not change over the K loop + a scalar offset per
+    // chunk/tap; out-of-image pixels get an offset beyond the buffer and read as zeros (hardware range
+    // check), so the loop carries no address arithmetic, no 64-bit pointers and no divergent branches
+    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(p.in), 0, (unsigned)((size_t)p.H * p.W * p.Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(p.wt_bf), 0, (unsigned)((size_t)9 * p.Cout * nchunks_all * WROWB), 0x00020000);
+    unsigned a_voff[C::A_PER_T];
+    int a_lds[C::A_PER_T];
 #pragma unroll
-        for (int i = 0; i < C::A_PER_T; ++i) {
-            const int u = tid + i * C::NT;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (u < C::A_UNITS) {
-                const int pix = u >> 3;
-                const int q = u & 7;
-                const int pr = pix / C::PW;
-                const int pc = pix - pr * C::PW;
-                const int gy = y0 - 1 + pr;
-                const int gx = x0 - 1 + pc;
-                if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                    v = *reinterpret_cast<const f32x4*>(p.in + ((size_t)gy * p.W + gx) * p.Cin + chunk * KC + q * 4);
-            }
-            ra[i] = v;
-        }
+    for (int i = 0; i < C::A_PER_T; ++i) {
+        const int u = tid + i * C::NT;
+        const int pix = u >> 3;
+        const int q = u & 7;
+        const int pr = pix / C::PW;
+        const int pc = pix - pr * C::PW;
+        const int gy = y0 - 1 + pr;
+        const int gx = x0 - 1 + pc;
+        const bool ok = (u < C::A_UNITS) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        a_voff[i] = ok ? (unsigned)(((gy * p.W + gx) * p.Cin + q * 4) * 4) : 0xFFFFFF00u;
+        a_lds[i] = (u < C::A_UNITS) ? pr * C::PROWB + pc * ROWB + q * 8 : -1;
+    }
+    unsigned b_voff[C::B_PER_T];
+    int b_lds[C::B_PER_T];
+#pragma unroll
+    for (int i = 0; i < C::B_PER_T; ++i) {
+        const int u = tid + i * C::NT;
+        const int n = u / 12;
+        const int q = u - n * 12;
+        b_voff[i] = (u < C::B_UNITS) ? (unsigned)(n * nchunks_all * WROWB + q * 16) : 0xFFFFFF00u;
+        b_lds[i] = (u < C::B_UNITS) ? n * ROWB + q * 16 : -1;
+    }
+
+    auto load_a = [&](int chunk) {
+        const int soff = chunk * KC * 4;
+#pragma unroll
+        for (int i = 0; i < C::A_PER_T; ++i)
+            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, a_voff[i], soff, 0));
     };
     // cut the staged fp32 values into their three bf16 pieces and write 8 bytes per piece
     auto store_a = [&]() {
 #pragma unroll
         for (int i = 0; i < C::A_PER_T; ++i) {
-            const int u = tid + i * C::NT;
-            if (u < C::A_UNITS) {
-                const int pix = u >> 3;
-                const int q = u & 7;
+            if (a_lds[i] >= 0) {
                 unsigned h[4], m[4], l[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) cut3(ra[i][k], h[k], m[k], l[k]);
-                unsigned char* row = ldsA + pix * ROWB + q * 8;
+                unsigned char* row = ldsA + a_lds[i];
                 *reinterpret_cast<u32x2*>(row) = u32x2{pack2(h[0], h[1]), pack2(h[2], h[3])};
                 *reinterpret_cast<u32x2*>(row + 64) = u32x2{pack2(m[0], m[1]), pack2(m[2], m[3])};
                 *reinterpret_cast<u32x2*>(row + 128) = u32x2{pack2(l[0], l[1]), pack2(l[2], l[3])};
@@ -136,29 +157,15 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
     };
     // weights: [tap][Cout][chunk][piece][32] bf16, i.e. 192 contiguous bytes per (tap, cout, chunk)
     auto load_b = [&](int chunk, int tap) {
-        const unsigned char* base = reinterpret_cast<const unsigned char*>(p.wt_bf) +
-                                    (((size_t)tap * p.Cout + n0) * nchunks_all + chunk) * WROWB;
+        const int soff = ((tap * p.Cout + n0) * nchunks_all + chunk) * WROWB;
 #pragma unroll
-        for (int i = 0; i < C::B_PER_T; ++i) {
-            const int u = tid + i * C::NT;
-            if (u < C::B_UNITS) {
-                const int n = u / 12;
-                const int q = u - n * 12;
-                rb[i] = *reinterpret_cast<const u32x4*>(base + (size_t)n * nchunks_all * WROWB + q * 16);
-            }
-        }
+        for (int i = 0; i < C::B_PER_T; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, b_voff[i], soff, 0);
     };
     auto store_b = [&](int buf) {
         unsigned char* dst = ldsB + buf * C::B_BYTES;
 #pragma unroll
-        for (int i = 0; i < C::B_PER_T; ++i) {
-            const int u = tid + i * C::NT;
-            if (u < C::B_UNITS) {
-                const int n = u / 12;
-                const int q = u - n * 12;
-                *reinterpret_cast<u32x4*>(dst + n * ROWB + q * 16) = rb[i];
-            }
-        }
+        for (int i = 0; i < C::B_PER_T; ++i)
+            if (b_lds[i] >= 0) *reinterpret_cast<u32x4*>(dst + b_lds[i]) = rb[i];
     };
 
     f32x16 acc[2][2];
@@ -172,8 +179,8 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
     // fragment addresses: lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8h + j], B[k = 8h + j][col r]
     const int prow = wm * 4 + (l31 >> 4);
     const int pcol = l31 & 15;
-    const int a_off0 = ((prow + 0) * C::PW + pcol) * ROWB + half * 16;
-    const int a_off1 = ((prow + 2) * C::PW + pcol) * ROWB + half * 16;
+    const int a_off0 = (prow + 0) * C::PROWB + pcol * ROWB + half * 16;
+    const int a_off1 = (prow + 2) * C::PROWB + pcol * ROWB + half * 16;
     const int b_off0 = (wn * 64 + l31) * ROWB + half * 16;
     const int b_off1 = (wn * 64 + 32 + l31) * ROWB + half * 16;
 
@@ -193,33 +200,47 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
                 load_b(c + 1, 0);
                 load_a(c + 1);
             }
-            const int tap_off = ((t / 3) * C::PW + (t % 3)) * ROWB;
+            const int tap_off = (t / 3) * C::PROWB + (t % 3) * ROWB;
             const unsigned char* bsrc = ldsB + cur * C::B_BYTES;
+            // both k-steps' fragments are requested before the first MFMA, so the second set lands while
+            // the first 24 MFMAs issue (two register sets: 2 x 12 fragments)
+            bf16x8 fa[2][2][3], fb[2][2][3];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 fa[2][3], fb[2][3];
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
-                    fa[0][s] = *reinterpret_cast<const bf16x8*>(ldsA + a_off0 + tap_off + s * 64 + ks * 32);
-                    fa[1][s] = *reinterpret_cast<const bf16x8*>(ldsA + a_off1 + tap_off + s * 64 + ks * 32);
-                    fb[0][s] = *reinterpret_cast<const bf16x8*>(bsrc + b_off0 + s * 64 + ks * 32);
-                    fb[1][s] = *reinterpret_cast<const bf16x8*>(bsrc + b_off1 + s * 64 + ks * 32);
+                    fa[ks][0][s] = *reinterpret_cast<const bf16x8*>(ldsA + a_off0 + tap_off + s * 64 + ks * 32);
+                    fa[ks][1][s] = *reinterpret_cast<const bf16x8*>(ldsA + a_off1 + tap_off + s * 64 + ks * 32);
+                    fb[ks][0][s] = *reinterpret_cast<const bf16x8*>(bsrc + b_off0 + s * 64 + ks * 32);
+                    fb[ks][1][s] = *reinterpret_cast<const bf16x8*>(bsrc + b_off1 + s * 64 + ks * 32);
                 }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
                 // smallest terms first; the six products of one (mt, nt) form one accumulation chain
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
                         f32x16 v = acc[mt][nt];
-                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][2], fb[nt][0], v, 0, 0, 0);
-                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][2], v, 0, 0, 0);
-                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[nt][1], v, 0, 0, 0);
-                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][1], fb[nt][0], v, 0, 0, 0);
-                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][1], v, 0, 0, 0);
-                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][0], fb[nt][0], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][2], fb[ks][nt][0], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][0], fb[ks][nt][2], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][1], fb[ks][nt][1], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][1], fb[ks][nt][0], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][0], fb[ks][nt][1], v, 0, 0, 0);
+                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][0], fb[ks][nt][0], v, 0, 0, 0);
                         acc[mt][nt] = v;
                     }
             }
+            // pin the order: 12 fragment reads (k-step 0), then the k-step-1 reads interleaved one per two
+            // MFMAs of k-step 0, then k-step 1's MFMAs (hipcc otherwise loads fragments just in time and
+            // exposes the LDS latency several times per k-step)
+            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+            for (int g = 0; g < 12; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
             cur ^= 1;
         }
     }
@@ -273,29 +294,30 @@ hipError_t conv_bf3_init_device() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, BfCfg<32, 64>::LDS_BYTES);
 }
 
-// one workgroup per CU here, so a layer needs >= ~200 tiles before split-K stops paying
+// One workgroup per CU: cost(S) = rounds of workgroups over the 256 CUs x chunks per workgroup.  Split the
+// channel chunks when that removes a partly filled round (e.g. 384 tiles: 2 rounds of 16 chunks -> 3 rounds
+// of 8); the ordered finish pass costs one extra read of S partial maps, so a split must save >= 12 %.
 int conv_bf3_ksplit(int H, int W, int Cin, int Cout) {
     const bool wide = (Cout % 128 == 0);
     const int th = wide ? 16 : 32, bn = wide ? 128 : 64;
     const long blocks = (long)((H + th - 1) / th) * ((W + 15) / 16) * (Cout / bn);
     const int nchunks = Cin / 32;
-    if (blocks >= 192 || nchunks < 2) return 1;
-    double best = 1e30;
-    for (int S = 1; S <= nchunks && S <= 16; S *= 2) {
-        if (nchunks % S) continue;
-        const double c = (double)((blocks * S + 255) / 256) * (nchunks / S);
-        if (c < best) best = c;
-    }
-    for (int S = 1; S <= nchunks && S <= 16; S *= 2) {
-        if (nchunks % S) continue;
-        const double c = (double)((blocks * S + 255) / 256) * (nchunks / S);
-        if (c <= best * 1.05) return S;
-    }
+    if (nchunks < 2) return 1;
+    auto cost = [&](int S) { return (double)((blocks * S + 255) / 256) * (nchunks / S); };
+    double best = cost(1);
+    for (int S = 2; S <= nchunks && S <= 16; S *= 2)
+        if (nchunks % S == 0 && cost(S) < best) best = cost(S);
+    if (best > 0.88 * cost(1)) return 1;
+    for (int S = 2; S <= nchunks && S <= 16; S *= 2)
+        if (nchunks % S == 0 && cost(S) <= best * 1.05) return S;
     return 1;
 }
 
 hipError_t launch_conv_bf3(const ConvParams& p0, hipStream_t stream) {
     if (p0.Cin % 32 != 0 || p0.Cout % 64 != 0 || !p0.wt_bf) return hipErrorInvalidValue;
+    // 32-bit buffer offsets: the input tensor must stay below 4 GiB (true up to L=3; callers fall back to
+    // conv_mfma.hip, which addresses with 64-bit pointers, beyond that)
+    if ((size_t)p0.H * p0.W * p0.Cin * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
     ConvParams p = p0;
     p.ksplit = 1;
     if (p.partial) {

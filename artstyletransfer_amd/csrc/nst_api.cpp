@@ -226,6 +226,12 @@ struct Timer {
 
 double conv_flops(int h, int w, int cin, int cout, int taps) { return 2.0 * h * w * (double)cin * cout * taps; }
 
+// 3x3 conv dispatch: bf16 3-piece kernel unless disabled or the tensor needs 64-bit addressing
+hipError_t launch_conv3(nst_ctx* ctx, const ConvParams& p, hipStream_t s) {
+    if (ctx->conv_bf3 && (size_t)p.H * p.W * p.Cin * 4 < 0xFFFFFF00ull) return launch_conv_bf3(p, s);
+    return launch_conv_mfma(p, 9, s);
+}
+
 // ---- network forward ----------------------------------------------------------------------------
 int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s, int last_layer = NL - 1) {
     {
@@ -241,7 +247,7 @@ int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s
         p.partial = a.splitk; p.partial_floats = a.splitk_floats; p.wt_bf = ctx->wf_bf[l];
         {
             Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, l);
-            HIPCHK(ctx, ctx->conv_bf3 ? launch_conv_bf3(p, s) : launch_conv_mfma(p, 9, s));
+            HIPCHK(ctx, launch_conv3(ctx, p, s));
         }
         const int pa = pool_index_after(l);
         if (pa >= 0 && l < last_layer) {
@@ -295,7 +301,7 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
         if (pk >= 0) {
             {
                 Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, -l);
-                HIPCHK(ctx, ctx->conv_bf3 ? launch_conv_bf3(p, s) : launch_conv_mfma(p, 9, s));
+                HIPCHK(ctx, launch_conv3(ctx, p, s));
             }
             // oth = g(pool[pk]); un-pool through act[l-1] with its ReLU mask -> cur
             Timer t(ctx, s, K_OTHER, 0);
@@ -321,7 +327,7 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
             p.mask = a.act[m];
             {
                 Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, -l);
-                HIPCHK(ctx, ctx->conv_bf3 ? launch_conv_bf3(p, s) : launch_conv_mfma(p, 9, s));
+                HIPCHK(ctx, launch_conv3(ctx, p, s));
             }
             float* tmp = cur; cur = oth; oth = tmp;
         }
