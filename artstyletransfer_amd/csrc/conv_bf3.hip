@@ -16,6 +16,8 @@
 // = 13 x 16 B: 16 consecutive rows start on 16 distinct 16-B slots -> conflict-free ds_read_b128 fragments.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "nst_kernels.h"
 
 namespace nst {
@@ -93,23 +95,13 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
     const int x0 = tx * C::TW;
     const int n0 = ct * BN;
 
-    const int nchunks_all = p.Cin / KC;
-    const int cps = nchunks_all / p.ksplit;
-    const int c_begin = blockIdx.y * cps;
-    const int c_end = c_begin + cps;
-
     f32x4 ra[C::A_PER_T];
     u32x4 rb[C::B_PER_T];
 
-    // buffer loads: 32-bit per-lane offsets that do not change over the K loop + a scalar offset per
-    // chunk/tap; out-of-image pixels get an offset beyond the buffer and read as zeros (hardware range
-    // check), so the loop carries no address arithmetic, no 64-bit pointers and no divergent branches
-    const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(p.in), 0, (unsigned)((size_t)p.H * p.W * p.Cin * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<void*>(p.wt_bf), 0, (unsigned)((size_t)9 * p.Cout * nchunks_all * WROWB), 0x00020000);
-    unsigned a_voff[C::A_PER_T];
+    // LDS destinations of this lane's staging units (fixed for the whole kernel)
     int a_lds[C::A_PER_T];
+    int a_pix_ok[C::A_PER_T];        // pixel offset (y*W + x) inside the image, or -1 outside / unused
+    int a_q[C::A_PER_T];
 #pragma unroll
     for (int i = 0; i < C::A_PER_T; ++i) {
         const int u = tid + i * C::NT;
@@ -120,26 +112,19 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
         const int gy = y0 - 1 + pr;
         const int gx = x0 - 1 + pc;
         const bool ok = (u < C::A_UNITS) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        a_voff[i] = ok ? (unsigned)(((gy * p.W + gx) * p.Cin + q * 4) * 4) : 0xFFFFFF00u;
+        a_pix_ok[i] = ok ? gy * p.W + gx : -1;
+        a_q[i] = q;
         a_lds[i] = (u < C::A_UNITS) ? pr * C::PROWB + pc * ROWB + q * 8 : -1;
     }
-    unsigned b_voff[C::B_PER_T];
-    int b_lds[C::B_PER_T];
+    int b_n[C::B_PER_T], b_q[C::B_PER_T], b_lds[C::B_PER_T];
 #pragma unroll
     for (int i = 0; i < C::B_PER_T; ++i) {
         const int u = tid + i * C::NT;
-        const int n = u / 12;
-        const int q = u - n * 12;
-        b_voff[i] = (u < C::B_UNITS) ? (unsigned)(n * nchunks_all * WROWB + q * 16) : 0xFFFFFF00u;
-        b_lds[i] = (u < C::B_UNITS) ? n * ROWB + q * 16 : -1;
+        b_n[i] = u / 12;
+        b_q[i] = u - b_n[i] * 12;
+        b_lds[i] = (u < C::B_UNITS) ? b_n[i] * ROWB + b_q[i] * 16 : -1;
     }
 
-    auto load_a = [&](int chunk) {
-        const int soff = chunk * KC * 4;
-#pragma unroll
-        for (int i = 0; i < C::A_PER_T; ++i)
-            ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, a_voff[i], soff, 0));
-    };
     // cut the staged fp32 values into their three bf16 pieces and write 8 bytes per piece
     auto store_a = [&]() {
 #pragma unroll
@@ -154,12 +139,6 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
                 *reinterpret_cast<u32x2*>(row + 128) = u32x2{pack2(l[0], l[1]), pack2(l[2], l[3])};
             }
         }
-    };
-    // weights: [tap][Cout][chunk][piece][32] bf16, i.e. 192 contiguous bytes per (tap, cout, chunk)
-    auto load_b = [&](int chunk, int tap) {
-        const int soff = ((tap * p.Cout + n0) * nchunks_all + chunk) * WROWB;
-#pragma unroll
-        for (int i = 0; i < C::B_PER_T; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, b_voff[i], soff, 0);
     };
     auto store_b = [&](int buf) {
         unsigned char* dst = ldsB + buf * C::B_BYTES;
@@ -183,67 +162,108 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
     const int a_off1 = (prow + 2) * C::PROWB + pcol * ROWB + half * 16;
     const int b_off0 = (wn * 64 + l31) * ROWB + half * 16;
     const int b_off1 = (wn * 64 + 32 + l31) * ROWB + half * 16;
-
-    load_a(c_begin);
-    load_b(c_begin, 0);
     int cur = 0;
-    for (int c = c_begin; c < c_end; ++c) {
-        if (c > c_begin) __syncthreads();
-        store_a();
+
+    // One K source = (activation tensor, its weights, NTAPS taps).  Source 0 is the 3x3 conv proper
+    // (9 taps); the optional source 1 is a 1x1 product with a second tensor of the same spatial size
+    // accumulated into the same tile (the Gram backward dF = F * S riding on the input-gradient launch).
+    // Loads are buffer loads: a 32-bit per-lane offset that does not change over the K loop plus a scalar
+    // offset per chunk/tap; out-of-image pixels get an offset beyond the buffer and read as zeros (hardware
+    // range check): no address arithmetic, 64-bit pointers or divergent branches inside the loop.
+    auto run_source = [&](auto ntaps_c, const float* src, int cin, const void* wts, int cb, int ce) {
+        constexpr int NTAPS = decltype(ntaps_c)::value;
+        const int nch = cin / KC;
+        const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(src), 0, (unsigned)((size_t)p.H * p.W * cin * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(wts), 0, (unsigned)((size_t)NTAPS * p.Cout * nch * WROWB), 0x00020000);
+        unsigned a_voff[C::A_PER_T], b_voff[C::B_PER_T];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            store_b(cur);
-            __syncthreads();
-            if (t + 1 < 9) {
-                load_b(c, t + 1);
-            } else if (c + 1 < c_end) {
-                load_b(c + 1, 0);
-                load_a(c + 1);
-            }
-            const int tap_off = (t / 3) * C::PROWB + (t % 3) * ROWB;
-            const unsigned char* bsrc = ldsB + cur * C::B_BYTES;
-            // both k-steps' fragments are requested before the first MFMA, so the second set lands while
-            // the first 24 MFMAs issue (two register sets: 2 x 12 fragments)
-            bf16x8 fa[2][2][3], fb[2][2][3];
+        for (int i = 0; i < C::A_PER_T; ++i)
+            a_voff[i] = (a_pix_ok[i] >= 0) ? (unsigned)((a_pix_ok[i] * cin + a_q[i] * 4) * 4) : 0xFFFFFF00u;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+        for (int i = 0; i < C::B_PER_T; ++i)
+            b_voff[i] = (b_lds[i] >= 0) ? (unsigned)(b_n[i] * nch * WROWB + b_q[i] * 16) : 0xFFFFFF00u;
+        auto load_a = [&](int chunk) {
+            const int soff = chunk * KC * 4;
 #pragma unroll
-                for (int s = 0; s < 3; ++s) {
-                    fa[ks][0][s] = *reinterpret_cast<const bf16x8*>(ldsA + a_off0 + tap_off + s * 64 + ks * 32);
-                    fa[ks][1][s] = *reinterpret_cast<const bf16x8*>(ldsA + a_off1 + tap_off + s * 64 + ks * 32);
-                    fb[ks][0][s] = *reinterpret_cast<const bf16x8*>(bsrc + b_off0 + s * 64 + ks * 32);
-                    fb[ks][1][s] = *reinterpret_cast<const bf16x8*>(bsrc + b_off1 + s * 64 + ks * 32);
+            for (int i = 0; i < C::A_PER_T; ++i)
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, a_voff[i], soff, 0));
+        };
+        // weights: [tap][Cout][chunk][piece][32] bf16, i.e. 192 contiguous bytes per (tap, cout, chunk)
+        auto load_b = [&](int chunk, int tap) {
+            const int soff = ((tap * p.Cout + n0) * nch + chunk) * WROWB;
+#pragma unroll
+            for (int i = 0; i < C::B_PER_T; ++i)
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, b_voff[i], soff, 0);
+        };
+
+        load_a(cb);
+        load_b(cb, 0);
+        for (int c = cb; c < ce; ++c) {
+            __syncthreads();     // every wave is done reading the previous patch (and B buffers of the last stage)
+            store_a();
+#pragma unroll
+            for (int t = 0; t < NTAPS; ++t) {
+                store_b(cur);
+                __syncthreads();
+                if (t + 1 < NTAPS) {
+                    load_b(c, t + 1);
+                } else if (c + 1 < ce) {
+                    load_b(c + 1, 0);
+                    load_a(c + 1);
                 }
+                // a 1-tap source reads the centre of the halo patch
+                const int tap_off = (NTAPS == 9) ? (t / 3) * C::PROWB + (t % 3) * ROWB : C::PROWB + ROWB;
+                const unsigned char* bsrc = ldsB + cur * C::B_BYTES;
+                // both k-steps' fragments are requested before they are needed: the second set lands while
+                // the first 24 MFMAs issue
+                bf16x8 fa[2][2][3], fb[2][2][3];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                // smallest terms first; the six products of one (mt, nt) form one accumulation chain
+                for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        f32x16 v = acc[mt][nt];
-                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][2], fb[ks][nt][0], v, 0, 0, 0);
-                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][0], fb[ks][nt][2], v, 0, 0, 0);
-                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][1], fb[ks][nt][1], v, 0, 0, 0);
-                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][1], fb[ks][nt][0], v, 0, 0, 0);
-                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][0], fb[ks][nt][1], v, 0, 0, 0);
-                        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][0], fb[ks][nt][0], v, 0, 0, 0);
-                        acc[mt][nt] = v;
+                    for (int s = 0; s < 3; ++s) {
+                        fa[ks][0][s] = *reinterpret_cast<const bf16x8*>(ldsA + a_off0 + tap_off + s * 64 + ks * 32);
+                        fa[ks][1][s] = *reinterpret_cast<const bf16x8*>(ldsA + a_off1 + tap_off + s * 64 + ks * 32);
+                        fb[ks][0][s] = *reinterpret_cast<const bf16x8*>(bsrc + b_off0 + s * 64 + ks * 32);
+                        fb[ks][1][s] = *reinterpret_cast<const bf16x8*>(bsrc + b_off1 + s * 64 + ks * 32);
                     }
-            }
-            // pin the order: 12 fragment reads (k-step 0), then the k-step-1 reads interleaved one per two
-            // MFMAs of k-step 0, then k-step 1's MFMAs (hipcc otherwise loads fragments just in time and
-            // exposes the LDS latency several times per k-step)
-            __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
 #pragma unroll
-            for (int g = 0; g < 12; ++g) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                for (int ks = 0; ks < 2; ++ks) {
+                    // smallest terms first; the six products of one (mt, nt) form one accumulation chain
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            f32x16 v = acc[mt][nt];
+                            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][2], fb[ks][nt][0], v, 0, 0, 0);
+                            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][0], fb[ks][nt][2], v, 0, 0, 0);
+                            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][1], fb[ks][nt][1], v, 0, 0, 0);
+                            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][1], fb[ks][nt][0], v, 0, 0, 0);
+                            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][0], fb[ks][nt][1], v, 0, 0, 0);
+                            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt][0], fb[ks][nt][0], v, 0, 0, 0);
+                            acc[mt][nt] = v;
+                        }
+                }
+                // pin the order: 12 fragment reads (k-step 0), then the k-step-1 reads interleaved one per two
+                // MFMAs of k-step 0, then k-step 1's MFMAs (hipcc otherwise loads fragments just in time and
+                // exposes the LDS latency several times per k-step)
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);
+#pragma unroll
+                for (int g = 0; g < 12; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
+                cur ^= 1;
             }
-            __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
-            cur ^= 1;
         }
-    }
+    };
+
+    const int nchunks_all = p.Cin / KC;
+    const int cps = nchunks_all / p.ksplit;
+    run_source(std::integral_constant<int, 9>{}, p.in, p.Cin, p.wt_bf, blockIdx.y * cps, blockIdx.y * cps + cps);
+    if (p.in2 && blockIdx.y == 0) run_source(std::integral_constant<int, 1>{}, p.in2, p.Cin2, p.wt2_bf, 0, p.Cin2 / KC);
 
     // epilogue: D[m][n]: n = lane&31, m = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (p.ksplit > 1) {
@@ -263,26 +283,56 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
         }
         return;
     }
+    const int words = p.Cout >> 5;          // ReLU bit-mask words per pixel
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int co = n0 + wn * 64 + nt * 32 + l31;
+        const int cw = (n0 + wn * 64 + nt * 32) >> 5;
         const float bv = p.bias ? p.bias[co] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int y = y0 + wm * 4 + mt * 2 + (m >> 4);
                 const int x = x0 + (m & 15);
-                if (y < p.H && x < p.W) {
-                    const size_t idx = ((size_t)y * p.W + x) * p.Cout + co;
-                    float v = acc[mt][nt][r] + bv;
-                    if (p.addend) v += p.addend[idx];
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.mask) v = (p.mask[idx] > 0.f) ? v : 0.f;
-                    p.out[idx] = v;
+                const bool inb = (y < p.H && x < p.W);
+                const size_t pix = (size_t)y * p.W + x;
+                const size_t idx = pix * p.Cout + co;
+                float v = acc[mt][nt][r] + bv;
+                if (p.addend && inb) v += p.addend[idx];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.bits_in) {
+                    // the 32 lanes of a half-wave read the same word: one bit per output channel
+                    const unsigned wv = inb ? p.bits_in[pix * words + cw] : 0u;
+                    v = ((wv >> l31) & 1u) ? v : 0.f;
+                } else if (p.mask) {
+                    v = (inb && p.mask[idx] > 0.f) ? v : 0.f;
+                }
+                if (p.bits_out) {
+                    // ReLU mask of this output for the backward pass: bit = lane, one word per half-wave
+                    const unsigned long long bal = __ballot(v > 0.f);
+                    if (l31 == 0 && inb) p.bits_out[pix * words + cw] = half ? (unsigned)(bal >> 32) : (unsigned)bal;
+                }
+                acc[mt][nt][r] = v;
+                if (inb) p.out[idx] = v;
+            }
+            if (p.pool_out) {
+                // 2x2/2 max pool of the tile rows (2 mt, 2 mt + 1): the four window elements sit in this
+                // lane's registers r, r+1, r+8, r+9
+                const int py = (y0 + wm * 4 + mt * 2) >> 1;
+                const int PH2 = p.H >> 1, PW2 = p.W >> 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 2 * j;
+                    const float mx = fmaxf(fmaxf(acc[mt][nt][r], acc[mt][nt][r + 1]),
+                                           fmaxf(acc[mt][nt][r + 8], acc[mt][nt][r + 9]));
+                    const int mcol = (r & 3) + 8 * (r >> 2) + 4 * half;      // column of register r (row 0 of the pair)
+                    const int px = (x0 + mcol) >> 1;
+                    if (py < PH2 && px < PW2) p.pool_out[((size_t)py * PW2 + px) * p.Cout + co] = mx;
                 }
             }
+        }
     }
 }
 

@@ -26,7 +26,8 @@ __host__ __device__ constexpr int tap_off(int k) {
 
 __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restrict__ x, int H, int W,
                                                           const float* __restrict__ wk,
-                                                          const float* __restrict__ bias, float* __restrict__ out) {
+                                                          const float* __restrict__ bias, float* __restrict__ out,
+                                                          unsigned* __restrict__ bits_out) {
     __shared__ float patch[3 * F_PLANE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -89,15 +90,21 @@ __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restric
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
                 const int y = y0 + wave * 4 + mt * 2 + (m >> 4);
                 const int xx = x0 + (m & 15);
-                if (y < H && xx < W) out[((size_t)y * W + xx) * 64 + co] = fmaxf(acc[mt][nt][r] + bv, 0.f);
+                const bool inb = (y < H && xx < W);
+                const float v = fmaxf(acc[mt][nt][r] + bv, 0.f);
+                if (inb) out[((size_t)y * W + xx) * 64 + co] = v;
+                if (bits_out) {
+                    const unsigned long long bal = __ballot(v > 0.f);
+                    if (l31 == 0 && inb) bits_out[((size_t)y * W + xx) * 2 + nt] = half ? (unsigned)(bal >> 32) : (unsigned)bal;
+                }
             }
     }
 }
 
 hipError_t launch_conv1_1_fwd(const float* x, int H, int W, const float* wk, const float* bias, float* out,
-                              hipStream_t stream) {
+                              unsigned* bits_out, hipStream_t stream) {
     const int blocks = ((H + F_TH - 1) / F_TH) * ((W + F_TW - 1) / F_TW);
-    hipLaunchKernelGGL(conv1_1_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, H, W, wk, bias, out);
+    hipLaunchKernelGGL(conv1_1_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, H, W, wk, bias, out, bits_out);
     return hipGetLastError();
 }
 

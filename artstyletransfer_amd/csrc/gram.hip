@@ -221,6 +221,7 @@ hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, floa
 __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ part, int nslabs, int C, int ts,
                                                           float divisor, const float* __restrict__ target, float coef,
                                                           float* __restrict__ gram_out, float* __restrict__ S,
+                                                          unsigned short* __restrict__ S_bf,
                                                           double* __restrict__ mse_partial) {
     __shared__ float sh[8][32];
     __shared__ double shd[32];
@@ -248,7 +249,21 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
             if (target) {
                 const float d = g - target[e];
                 sq = (double)d * (double)d;
-                if (S) S[e] = coef * d;
+                const float sv = coef * d;
+                if (S) S[e] = sv;
+                if (S_bf) {
+                    // the same value cut into three bf16 pieces in conv_bf3's weight layout
+                    // [row i][chunk j/32][piece][j%32] (a 1x1 "conv" weight with Cout = Cin = C)
+                    const int i = (int)(e / C), j = (int)(e % C);
+                    const unsigned uh = __float_as_uint(sv) & 0xFFFF0000u;
+                    const float r1 = sv - __uint_as_float(uh);
+                    const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
+                    const float r2 = r1 - __uint_as_float(um);
+                    const size_t base = (((size_t)i * (C / 32) + j / 32) * 3) * 32 + (j & 31);
+                    S_bf[base] = (unsigned short)(uh >> 16);
+                    S_bf[base + 32] = (unsigned short)(um >> 16);
+                    S_bf[base + 64] = (unsigned short)(__float_as_uint(r2) >> 16);
+                }
             }
         }
         shd[el] = sq;
@@ -264,9 +279,9 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
 int gram_finish_blocks(int C) { return (int)(((size_t)C * C + 31) / 32); }
 
 hipError_t launch_gram_finish(const float* part, int nslabs, int C, float divisor, const float* target, float coef,
-                              float* gram_out, float* S, double* mse_partial, hipStream_t stream) {
+                              float* gram_out, float* S, unsigned short* S_bf, double* mse_partial, hipStream_t stream) {
     hipLaunchKernelGGL(gram_finish_kernel, dim3(gram_finish_blocks(C)), dim3(256), 0, stream, part, nslabs, C,
-                       gram_ts(C), divisor, target, coef, gram_out, S, mse_partial);
+                       gram_ts(C), divisor, target, coef, gram_out, S, (C % 32 == 0) ? S_bf : nullptr, mse_partial);
     return hipGetLastError();
 }
 

@@ -39,6 +39,9 @@ struct ActSet {                 // activations of one forward pass, NHWC
     float* pool[4] = {};
     float* splitk = nullptr;     // split-K partial sums of the small-spatial conv layers
     size_t splitk_floats = 0;
+    unsigned* bits[NL] = {};     // ReLU bit-masks ([h*w][C/32] words) of the layers whose mask the backward reads
+    bool bits_valid[NL] = {};    // written by the last forward pass (false when that layer ran split-K / fp32)
+    bool pooled[4] = {};         // pool[k] already produced by the conv epilogue of the last forward pass
     size_t bytes = 0;
 };
 
@@ -57,6 +60,7 @@ struct LevelWs {
     size_t content_n = 0;
     float* gram_t[5] = {};
     float* S[5] = {};
+    unsigned short* S_bf[5] = {};
     float* gram_part = nullptr;
     size_t gram_part_floats = 0;
     double* style_partial[5] = {};
@@ -159,6 +163,14 @@ int alloc_acts(nst_ctx* ctx, ActSet& a, int h, int w) {
         if (fwd > px * kCout[l] && fwd > need) need = fwd;
         if (bwd > px * kCin[l] && bwd > need) need = bwd;
     }
+    // layers m whose ReLU mask a non-pooling input-gradient launch consumes
+    const int mask_layers[8] = {0, 2, 4, 5, 6, 8, 9, 10};
+    for (int k = 0; k < 8; ++k) {
+        const int m = mask_layers[k];
+        const size_t nw = (size_t)a.h[m] * a.w[m] * (kCout[m] / 32);
+        NSTCHK(dev_alloc_t(ctx, &a.bits[m], nw));
+        a.bytes += nw * 4;
+    }
     a.splitk_floats = need;
     if (need) {
         NSTCHK(dev_alloc_t(ctx, &a.splitk, need));
@@ -170,6 +182,7 @@ void free_acts(nst_ctx* ctx, ActSet& a) {
     for (int l = 0; l < NL; ++l) { dev_free(a.act[l]); a.act[l] = nullptr; }
     for (int k = 0; k < 4; ++k) { dev_free(a.pool[k]); a.pool[k] = nullptr; }
     dev_free(a.splitk); a.splitk = nullptr; a.splitk_floats = 0;
+    for (int l = 0; l < NL; ++l) { dev_free(a.bits[l]); a.bits[l] = nullptr; a.bits_valid[l] = false; }
     if (ctx->bytes >= a.bytes) ctx->bytes -= a.bytes;
     a.bytes = 0;
 }
@@ -232,11 +245,24 @@ hipError_t launch_conv3(nst_ctx* ctx, const ConvParams& p, hipStream_t s) {
     return launch_conv_mfma(p, 9, s);
 }
 
+bool uses_bf3(const nst_ctx* ctx, const ConvParams& p) {
+    return ctx->conv_bf3 && (size_t)p.H * p.W * p.Cin * 4 < 0xFFFFFF00ull;
+}
+bool bf3_unsplit(const nst_ctx* ctx, const ConvParams& p) {
+    if (!uses_bf3(ctx, p)) return false;
+    const int S = conv_bf3_ksplit(p.H, p.W, p.Cin, p.Cout);
+    return !(p.partial && S > 1 && (size_t)S * p.H * p.W * p.Cout <= p.partial_floats);
+}
+
 // ---- network forward ----------------------------------------------------------------------------
 int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s, int last_layer = NL - 1) {
+    for (int l = 0; l < NL; ++l) a.bits_valid[l] = false;
+    for (int k = 0; k < 4; ++k) a.pooled[k] = false;
     {
         Timer t(ctx, s, K_CONV1, conv_flops(h, w, 3, 64, 9));
-        HIPCHK(ctx, launch_conv1_1_fwd(x, h, w, ctx->w11k, ctx->bias[0], a.act[0], s));
+        unsigned* bits = ctx->conv_bf3 ? a.bits[0] : nullptr;
+        HIPCHK(ctx, launch_conv1_1_fwd(x, h, w, ctx->w11k, ctx->bias[0], a.act[0], bits, s));
+        a.bits_valid[0] = bits != nullptr;
     }
     for (int l = 1; l <= last_layer; ++l) {
         const int pk = pool_index_after(l - 1);
@@ -245,14 +271,24 @@ int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s
         p.in = in; p.wt = ctx->wf[l]; p.bias = ctx->bias[l]; p.addend = nullptr; p.mask = nullptr; p.out = a.act[l];
         p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCin[l]; p.Cout = kCout[l]; p.relu = 1;
         p.partial = a.splitk; p.partial_floats = a.splitk_floats; p.wt_bf = ctx->wf_bf[l];
+        const int pa = pool_index_after(l);
+        const bool fuse = bf3_unsplit(ctx, p);        // the epilogue extras exist in the unsplit bf3 kernel only
+        if (fuse) {
+            p.bits_out = a.bits[l];                   // nullptr for layers whose mask nobody reads
+            if (pa >= 0 && l < last_layer) p.pool_out = a.pool[pa];
+        }
         {
             Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, l);
             HIPCHK(ctx, launch_conv3(ctx, p, s));
         }
-        const int pa = pool_index_after(l);
+        a.bits_valid[l] = fuse && a.bits[l] != nullptr;
         if (pa >= 0 && l < last_layer) {
-            Timer t(ctx, s, K_OTHER, 0);
-            HIPCHK(ctx, launch_maxpool_fwd(a.act[l], a.h[l], a.w[l], kCout[l], a.pool[pa], s));
+            if (p.pool_out) {
+                a.pooled[pa] = true;
+            } else {
+                Timer t(ctx, s, K_OTHER, 0);
+                HIPCHK(ctx, launch_maxpool_fwd(a.act[l], a.h[l], a.w[l], kCout[l], a.pool[pa], s));
+            }
         }
     }
     return NST_OK;
@@ -261,6 +297,7 @@ int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s
 // gradient injected at a tap layer, w.r.t. its post-ReLU activation
 struct Inject {
     const float* S = nullptr;        // Gram backward: dF = F * S (1x1 conv of the activation itself)
+    const void* S_bf = nullptr;      // the same S cut into bf16 pieces (conv_bf3 weight layout), if available
     const float* direct = nullptr;   // or a ready NHWC gradient
     bool content = false;            // or the content MSE gradient (closure only)
 };
@@ -310,7 +347,13 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
         } else {
             const int m = l - 1;   // the layer whose activation this gradient flows into
             const Inject& in = inj[m];
-            if (in.S) {
+            const bool fuse = bf3_unsplit(ctx, p);
+            double extra_flops = 0;
+            if (in.S && in.S_bf && fuse) {
+                // Gram backward rides on this launch as a second K source: acc += act[m] * S
+                p.in2 = a.act[m]; p.Cin2 = kCout[m]; p.wt2_bf = in.S_bf;
+                extra_flops = conv_flops(a.h[m], a.w[m], kCout[m], kCout[m], 1);
+            } else if (in.S) {
                 ConvParams q{};
                 q.in = a.act[m]; q.wt = in.S; q.out = oth;
                 q.H = a.h[m]; q.W = a.w[m]; q.Cin = kCout[m]; q.Cout = kCout[m];
@@ -324,9 +367,10 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
             } else if (in.direct) {
                 p.addend = in.direct;
             }
-            p.mask = a.act[m];
+            if (fuse && a.bits_valid[m]) p.bits_in = a.bits[m];
+            else p.mask = a.act[m];
             {
-                Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, -l);
+                Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9) + extra_flops, p.H, p.W, p.Cin, p.Cout, 9, -l);
                 HIPCHK(ctx, launch_conv3(ctx, p, s));
             }
             float* tmp = cur; cur = oth; oth = tmp;
@@ -340,14 +384,14 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
 }
 
 int gram_of(nst_ctx* ctx, const float* f_nhwc, size_t N, int C, float divisor, float* part, const float* target,
-            float coef, float* gram_out, float* S, double* mse_partial, hipStream_t s) {
+            float coef, float* gram_out, float* S, unsigned short* S_bf, double* mse_partial, hipStream_t s) {
     const int ns = gram_nsplit(C, N);
     {
         Timer t(ctx, s, K_GRAM, 2.0 * (double)N * C * C);
         HIPCHK(ctx, launch_gram_partial(f_nhwc, N, C, ns, part, s));
     }
     Timer t(ctx, s, K_OTHER, 0);
-    HIPCHK(ctx, launch_gram_finish(part, gram_nslabs(C, ns), C, divisor, target, coef, gram_out, S, mse_partial, s));
+    HIPCHK(ctx, launch_gram_finish(part, gram_nslabs(C, ns), C, divisor, target, coef, gram_out, S, S_bf, mse_partial, s));
     return NST_OK;
 }
 
@@ -365,7 +409,7 @@ size_t gram_part_floats_for(int h, int w) {
 void free_level(nst_ctx* ctx, LevelWs& L) {
     free_acts(ctx, L.acts);
     dev_free(L.gbuf[0]); dev_free(L.gbuf[1]); dev_free(L.xl); dev_free(L.gxl); dev_free(L.content_t);
-    for (int k = 0; k < 5; ++k) { dev_free(L.gram_t[k]); dev_free(L.S[k]); dev_free(L.style_partial[k]); }
+    for (int k = 0; k < 5; ++k) { dev_free(L.gram_t[k]); dev_free(L.S[k]); dev_free(L.S_bf[k]); dev_free(L.style_partial[k]); }
     dev_free(L.gram_part); dev_free(L.content_partial); dev_free(L.tv_partial); dev_free(L.tv_means);
     if (L.stream) (void)hipStreamDestroy(L.stream);
     if (L.done) (void)hipEventDestroy(L.done);
@@ -541,6 +585,7 @@ int nst_job_configure(nst_ctx* ctx, int levels_num, int H0, int W0) {
             const int C = kCout[kStyleLayer[k]];
             NSTCHK(dev_alloc_t(ctx, &L.gram_t[k], (size_t)C * C));
             NSTCHK(dev_alloc_t(ctx, &L.S[k], (size_t)C * C));
+            NSTCHK(dev_alloc_t(ctx, &L.S_bf[k], (size_t)C * C * 3));
             NSTCHK(dev_alloc_t(ctx, &L.style_partial[k], gram_finish_blocks(C)));
         }
         L.gram_part_floats = gram_part_floats_for(h, w);
@@ -578,7 +623,7 @@ int nst_level_set_targets(nst_ctx* ctx, int level, const float* content, const f
         const int C = kCout[l];
         const size_t N = (size_t)sa.h[l] * sa.w[l];
         r = gram_of(ctx, sa.act[l], N, C, (float)((double)C * sa.h[l] * sa.w[l]), part, nullptr, 0.f, L.gram_t[k],
-                    nullptr, nullptr, s);
+                    nullptr, nullptr, nullptr, s);
     }
     hipError_t e = hipStreamSynchronize(s);
     free_acts(ctx, sa);
@@ -655,8 +700,9 @@ int nst_closure_levels(nst_ctx* ctx, const float* x, float cw, float sw, float t
             // style = mean_k mse(G_k, Gt_k); dL/dG = sw/5 * 2 (G-Gt)/C^2; dF = 2 * dL/dG * F / (C h w)
             const float coef = (float)((double)sw * 4.0 / (5.0 * (double)C * C * chw));
             NSTCHK(gram_of(ctx, L.acts.act[l], N, C, (float)chw, L.gram_part, L.gram_t[k], coef, nullptr, L.S[k],
-                           L.style_partial[k], s));
+                           L.S_bf[k], L.style_partial[k], s));
             inj[l].S = L.S[k];
+            inj[l].S_bf = L.S_bf[k];
         }
         inj[kContentLayer].content = true;
         ContentJob cj{L.content_t, L.content_n, (float)((double)cw * 2.0 / (double)L.content_n), L.content_partial};
@@ -810,7 +856,7 @@ int nst_gram(nst_ctx* ctx, const float* f, int C, int h, int w, int normalize, f
     if (r == NST_OK) r = dev_alloc_t(ctx, &part, (size_t)gram_nsplit(C, N) * C * C);
     if (r == NST_OK && launch_chw_to_hwc(f, C, h, w, nhwc, s) != hipSuccess) r = fail(ctx, NST_E_HIP, "chw_to_hwc launch failed");
     if (r == NST_OK)
-        r = gram_of(ctx, nhwc, N, C, normalize ? (float)((double)C * h * w) : 1.f, part, nullptr, 0.f, gram, nullptr, nullptr, s);
+        r = gram_of(ctx, nhwc, N, C, normalize ? (float)((double)C * h * w) : 1.f, part, nullptr, 0.f, gram, nullptr, nullptr, nullptr, s);
     hipError_t e = hipStreamSynchronize(s);
     dev_free(nhwc); dev_free(part);
     if (r != NST_OK) return r;

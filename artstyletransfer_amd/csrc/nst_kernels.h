@@ -22,6 +22,13 @@ struct ConvParams {
     float* partial;       // split-K workspace (nullable): [ksplit][H][W][Cout]
     size_t partial_floats;
     int ksplit;           // filled by the launcher
+    // conv_bf3 only ------------------------------------------------------------------------------
+    const float* in2;     // optional second K source [H][W][Cin2], accumulated as a 1x1 product with wt2_bf
+    int Cin2;
+    const void* wt2_bf;   // [1][Cout][Cin2/32][3][32] bf16
+    unsigned* bits_out;   // optional: ReLU bit-mask of the output, [H*W][Cout/32] words (bit = channel & 31)
+    const unsigned* bits_in;  // optional: replaces `mask` (same layout, of the tensor the gradient flows into)
+    float* pool_out;      // optional: 2x2/2 max-pooled output [H/2][W/2][Cout]
 };
 
 // conv_mfma.hip
@@ -39,8 +46,9 @@ int conv_bf3_ksplit(int H, int W, int Cin, int Cout);
 
 // conv_first.hip: conv1_1 (3 -> 64) forward from the planar image, and its input gradient
 // wk: [28][64] (k = c*9 + ky*3 + kx, row 27 zero); bias [64]; out NHWC 64, ReLU applied.
+// bits_out (nullable): ReLU bit-mask of the output, [H*W][2] words
 hipError_t launch_conv1_1_fwd(const float* x, int H, int W, const float* wk, const float* bias, float* out,
-                              hipStream_t stream);
+                              unsigned* bits_out, hipStream_t stream);
 // g: [H][W][64] gradient w.r.t. the pre-ReLU conv1_1 output; wd: [9][64][4] flipped taps
 // (wd[t][co][c] = W[co][c][2-ky][2-kx], c = 3 unused 0); gx planar (3,H,W), overwritten.
 hipError_t launch_conv1_1_dgrad(const float* g, int H, int W, const float* wd, float* gx, hipStream_t stream);
@@ -111,7 +119,7 @@ hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, floa
 int gram_nslabs(int C, int nsplit);
 int gram_finish_blocks(int C);
 hipError_t launch_gram_finish(const float* part, int nslabs, int C, float divisor, const float* target, float coef,
-                              float* gram_out, float* S, double* mse_partial, hipStream_t stream);
+                              float* gram_out, float* S, unsigned short* S_bf, double* mse_partial, hipStream_t stream);
 
 // vector_ops.hip: optimiser arithmetic over the n pixel floats ---------------------------------------
 constexpr int RED_BLOCKS = 256;
