@@ -54,6 +54,7 @@ SYMBOLS = {
     "nst_bicubic_half_backward": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void]),
     "nst_prepare_img": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void, c_void]),
     "nst_unprepare_img": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void, c_void]),
+    "nst_conv_mode": (C.c_int, [c_void]),
     "nst_ctx_bytes": (C.c_int, [c_void, C.POINTER(C.c_size_t)]),
     "nst_set_timing": (C.c_int, [c_void, C.c_int]),
     "nst_last_closure_ms": (C.c_int, [c_void, C.POINTER(C.c_float)]),

@@ -553,6 +553,8 @@ void nst_ctx_destroy(nst_ctx* ctx) {
     delete ctx;
 }
 
+int nst_conv_mode(const nst_ctx* ctx) { return ctx ? ctx->conv_bf3 : -1; }
+
 int nst_ctx_bytes(const nst_ctx* ctx, size_t* bytes) {
     if (!ctx || !bytes) return fail(nullptr, NST_E_ARG, "null argument");
     *bytes = ctx->bytes;

@@ -115,6 +115,10 @@ class StyleEngine:
                                                          _ptr(losses), _stream(self.device)), "nst_closure_levels")
         return grad, losses
 
+    def conv_mode(self) -> str:
+        """'bf16x3' (3-piece bf16 operands on the bf16 matrix pipe, fp32 accumulate) or 'f32' (fp32 MFMA)."""
+        return "bf16x3" if self.lib.nst_conv_mode(self.ctx) == 1 else "f32"
+
     def bytes(self) -> int:
         n = C.c_size_t()
         _lib.check(self.ctx, self.lib.nst_ctx_bytes(self.ctx, C.byref(n)), "nst_ctx_bytes")

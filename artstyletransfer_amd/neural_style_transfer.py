@@ -129,13 +129,43 @@ class NeuralStyleTransfer:
                     raise
 
             loop = asyncio.get_running_loop()
-            while step < iters_num:
-                info, rows = await loop.run_in_executor(None, one_step)
-                step = info.total_closures
-                if VERBOSE:
-                    for r in rows:
-                        print(f"{self.__optimizer_name} | {init_img_name} | lr={info.lr:.4f} | total loss={r[-1]:.3e}")
-                yield unprepare_img(optimizing_img), step
+            # Per-step yield (reference :207-208): the image is un-prepared into its own device buffer, copied to
+            # pinned host memory on a side stream, and the NEXT optimiser step is started before that copy is
+            # awaited, so the 4*3*H*W-byte D2H hides under the next closures.
+            host = [torch.empty((h0, w0, 3), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+            copy_stream = torch.cuda.Stream(device=dev)
+            k = 0
+            pending = loop.run_in_executor(None, one_step) if step < iters_num else None
+            try:
+                while pending is not None:
+                    info, rows = await pending
+                    pending = None
+                    step = info.total_closures
+                    if VERBOSE:
+                        for r in rows:
+                            print(f"{self.__optimizer_name} | {init_img_name} | lr={info.lr:.4f} | total loss={r[-1]:.3e}")
+                    with torch.cuda.device(dev):
+                        snap = engine.unprepare_img(optimizing_img)      # ordered before the next step on the stream
+                        ready = torch.cuda.Event()
+                        ready.record()
+                        if step < iters_num:
+                            pending = loop.run_in_executor(None, one_step)
+                        with torch.cuda.stream(copy_stream):
+                            copy_stream.wait_event(ready)
+                            host[k].copy_(snap, non_blocking=True)
+                            snap.record_stream(copy_stream)
+                            done = torch.cuda.Event()
+                            done.record()
+                    await loop.run_in_executor(None, done.synchronize)
+                    img = host[k].numpy().copy()
+                    k ^= 1
+                    yield img, step
+            finally:
+                if pending is not None:          # the consumer stopped early: let the running step finish
+                    try:
+                        await pending
+                    except Exception:
+                        pass
             optimizer.close()
         finally:
             engine.close()

@@ -30,7 +30,25 @@ if ROOT not in sys.path:
 import numpy as np
 import torch
 
-FP32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: 256 CU x 2.4 GHz x 256 flop/clk (v_mfma_f32_32x32x2_f32)
+# MI355X_MICROARCH.md dense matrix peaks: fp32 MFMA 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32), bf16 MFMA ~2500 TFLOP/s.
+# In the default conv mode every fp32 product is evaluated as 6 bf16 MFMA products (3-piece exact operand split),
+# so the matrix pipe executes 6x the algorithmic FLOPs and is priced against the bf16 peak.
+MFMA_PEAK = {"f32": 157.3, "bf16x3": 2500.0}
+MFMA_WORK_FACTOR = {"f32": 1.0, "bf16x3": 6.0}
+
+
+def mfma_roofline(mode, algorithmic_flops, ms, launches, extra=None):
+    alg = algorithmic_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    hw = alg * MFMA_WORK_FACTOR[mode]
+    out = {"bound": "mfma", "kernel": "conv_bf3_kernel" if mode == "bf16x3" else "conv_mfma_kernel",
+           "what": "3x3 conv forward + input gradient (+ fused Gram backward)",
+           "mfma_dtype": "bf16 (3 exact pieces per fp32 operand, 6 MFMAs per product, fp32 accumulate)" if mode == "bf16x3" else "f32",
+           "achieved": hw, "peak": MFMA_PEAK[mode], "unit": "TFLOP/s", "frac": hw / MFMA_PEAK[mode],
+           "algorithmic_tflops": alg, "traffic": None, "launches": launches, "avg_launch_ms": ms / max(launches, 1),
+           "flops_per_launch_avg": algorithmic_flops / max(launches, 1)}
+    if extra:
+        out.update(extra)
+    return out
 
 
 def build_job(levels_num: int, seed_shift: int, device):
@@ -104,10 +122,8 @@ def one_stream_pass(args, cfg, closures: int = 6):
     torch.cuda.synchronize()
     ms, n, fl = eng.timing_totals(0)
     cms, cn, _ = eng.timing_totals(-1)
-    ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    res = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-           "frac": ach / FP32_MFMA_PEAK_TFLOPS, "launches": n, "avg_launch_ms": ms / max(n, 1),
-           "closure_ms": cms / max(cn, 1), "conv3x3_ms_per_closure": ms / max(cn, 1)}
+    res = mfma_roofline(eng.conv_mode(), fl, ms, n, {"closure_ms": cms / max(cn, 1),
+                                                     "conv3x3_ms_per_closure": ms / max(cn, 1)})
     eng.close()
     return res
 
@@ -151,20 +167,39 @@ def main():
         opt.shard_levels(rank, world, dist)
     cw, sw, tvw = cfg.content_weight, cfg.style_weight, cfg.tv_weight
     H, W = eng.shape
-    img_dev = None
-    img_host = torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True)
+    # per-step image yield as NeuralStyleTransfer.process does it: un-prepare on the device, D2H into pinned
+    # memory on a side stream, so the copy of step k runs under the closures of step k+1; it is awaited before
+    # the next yield (two host buffers)
+    img_host = [torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+    copy_stream = torch.cuda.Stream()
+    copy_done = [None, None]
     per_step = 2 if args.optimizer == "lbfgs" else 1
 
     def run(closures: int):
         done = 0
         last = None
+        k = 0
         while done < closures:
             info, rows = opt.step(x, cw, sw, tvw, want_losses=True)
             done += info.closures
             last = rows
             if not args.no_yield:
-                img_host.copy_(eng.unprepare_img(x), non_blocking=True)
-                torch.cuda.current_stream().synchronize()
+                snap = eng.unprepare_img(x)
+                ready = torch.cuda.Event()
+                ready.record()
+                if copy_done[k] is not None:
+                    copy_done[k].synchronize()           # the consumer is done with this host buffer
+                with torch.cuda.stream(copy_stream):
+                    copy_stream.wait_event(ready)
+                    img_host[k].copy_(snap, non_blocking=True)
+                    snap.record_stream(copy_stream)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                copy_done[k] = ev
+                k ^= 1
+        for ev in copy_done:
+            if ev is not None:
+                ev.synchronize()
         return done, last
 
     def barrier():
@@ -201,7 +236,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32 via bf16x3 split (6 bf16 MFMAs per product, f32 accumulate)" if eng.conv_mode() == "bf16x3" else "f32",
             "data": "synthetic",
             "config": {"workload": f"pyramid style transfer, levels_num={args.levels} "
                                    f"({'+'.join(f'{W >> l}x{H >> l}' for l in range(args.levels))}), "
@@ -222,12 +257,7 @@ def main():
             gms, gn, gfl = eng.timing_totals(1)
             oms, on, _ = eng.timing_totals(3)
             c1ms, c1n, c1fl = eng.timing_totals(2)
-            ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            out["roofline"] = {"bound": "mfma", "kernel": "conv_mfma_kernel (3x3 fp32 MFMA conv, forward + input gradient)",
-                               "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                               "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                               "launches": n, "avg_launch_ms": ms / max(n, 1),
-                               "flops_per_launch_avg": fl / max(n, 1)}
+            out["roofline"] = mfma_roofline(eng.conv_mode(), fl, ms, n)
             out["kernel_ms_per_closure"] = {
                 "closure": cms / max(cn, 1), "conv3x3_mfma": ms / max(cn, 1), "gram_mfma": gms / max(cn, 1),
                 "conv1_1": c1ms / max(cn, 1), "streaming": oms / max(cn, 1)}

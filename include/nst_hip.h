@@ -139,6 +139,11 @@ int nst_bicubic_half_backward(nst_ctx* ctx, const float* gy, int C, int h, int w
 int nst_prepare_img(nst_ctx* ctx, const float* hwc, int h, int w, float* chw, void* stream);
 int nst_unprepare_img(nst_ctx* ctx, const float* chw, int h, int w, float* hwc, void* stream);
 
+/* arithmetic of the 3x3 convolutions: 1 = bf16 matrix pipe, both operands cut into three bf16 pieces that
+ * sum to the fp32 value exactly, 6 MFMAs per product, fp32 accumulate (default; fp32-level error);
+ * 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32; environment NST_CONV=f32 at context creation). */
+int nst_conv_mode(const nst_ctx* ctx);
+
 /* workspace bytes currently held by the context (activations, gradients, history, targets) */
 int nst_ctx_bytes(const nst_ctx* ctx, size_t* bytes);
 

