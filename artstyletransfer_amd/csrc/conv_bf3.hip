@@ -70,8 +70,9 @@ __device__ __forceinline__ unsigned pack2(unsigned first, unsigned second) {
 
 }  // namespace
 
+// the whole workgroup program; (sp, ct, split) = spatial tile, output-channel tile, K split of this workgroup
 template <int TH, int BN>
-__global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
+__device__ __forceinline__ void conv_bf3_body(const ConvParams& p, const int sp, const int ct, const int split) {
     using C = BfCfg<TH, BN>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ldsA = smem;
@@ -85,10 +86,6 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
     const int half = lane >> 5;
     const int l31 = lane & 31;
 
-    const int n_ct = p.Cout / BN;
-    const int bid = blockIdx.x;
-    const int ct = bid % n_ct;
-    const int sp = bid / n_ct;
     const int ty = sp / p.tiles_x;
     const int tx = sp - ty * p.tiles_x;
     const int y0 = ty * TH;
@@ -262,12 +259,12 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
 
     const int nchunks_all = p.Cin / KC;
     const int cps = nchunks_all / p.ksplit;
-    run_source(std::integral_constant<int, 9>{}, p.in, p.Cin, p.wt_bf, blockIdx.y * cps, blockIdx.y * cps + cps);
-    if (p.in2 && blockIdx.y == 0) run_source(std::integral_constant<int, 1>{}, p.in2, p.Cin2, p.wt2_bf, 0, p.Cin2 / KC);
+    run_source(std::integral_constant<int, 9>{}, p.in, p.Cin, p.wt_bf, split * cps, split * cps + cps);
+    if (p.in2 && split == 0) run_source(std::integral_constant<int, 1>{}, p.in2, p.Cin2, p.wt2_bf, 0, p.Cin2 / KC);
 
     // epilogue: D[m][n]: n = lane&31, m = (r&3) + 8*(r>>2) + 4*(lane>>5)
     if (p.ksplit > 1) {
-        float* dst = p.partial + (size_t)blockIdx.y * p.H * p.W * p.Cout;
+        float* dst = p.partial + (size_t)split * p.H * p.W * p.Cout;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int co = n0 + wn * 64 + nt * 32 + l31;
@@ -336,12 +333,70 @@ __global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
     }
 }
 
+template <int TH, int BN>
+__global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
+    const int n_ct = p.Cout / BN;
+    conv_bf3_body<TH, BN>(p, blockIdx.x / n_ct, blockIdx.x % n_ct, blockIdx.y);
+}
+
+// One launch = one layer over several images (the pyramid levels of a closure): same weights, same channel
+// counts, each image with its own tensors and size.  Workgroups are numbered image by image, so the few
+// tiles of the small levels fill the tail of the big level's grid instead of running as under-filled
+// launches of their own.
+template <int TH, int BN>
+__global__ __launch_bounds__(512) void conv_bf3_batch_kernel(ConvBatch b) {
+    const int n_ct = b.Cout / BN;
+    const int sp_all = blockIdx.x / n_ct;
+    int i = 0;
+    while (i + 1 < b.n && sp_all >= b.img[i].tile_end) ++i;
+    const ConvImage& im = b.img[i];
+    ConvParams p;
+    p.in = im.in; p.wt = nullptr; p.wt_bf = b.wt_bf; p.bias = b.bias; p.addend = im.addend; p.mask = im.mask; p.out = im.out;
+    p.H = im.H; p.W = im.W; p.Cin = b.Cin; p.Cout = b.Cout; p.relu = b.relu;
+    p.tiles_x = im.tiles_x; p.tiles_y = 0; p.partial = nullptr; p.partial_floats = 0; p.ksplit = 1;
+    p.in2 = im.in2; p.Cin2 = b.Cin2; p.wt2_bf = im.wt2_bf; p.bits_out = im.bits_out; p.bits_in = im.bits_in;
+    p.pool_out = im.pool_out;
+    conv_bf3_body<TH, BN>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), blockIdx.x % n_ct, 0);
+}
+
 hipError_t conv_bf3_init_device() {
+    constexpr int lds_w = BfCfg<16, 128>::LDS_BYTES, lds_n = BfCfg<32, 64>::LDS_BYTES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<16, 128>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, BfCfg<16, 128>::LDS_BYTES);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<32, 64>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, BfCfg<32, 64>::LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_w);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<32, 64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_n);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_batch_kernel<16, 128>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_w);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_batch_kernel<32, 64>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_n);
+    return e;
+}
+
+// fills tiles_x / tile_end of every image; returns the number of workgroups
+hipError_t launch_conv_bf3_batch(const ConvBatch& b0, hipStream_t stream) {
+    if (b0.n < 1 || b0.n > 8 || b0.Cin % 32 != 0 || b0.Cout % 64 != 0 || !b0.wt_bf) return hipErrorInvalidValue;
+    ConvBatch b = b0;
+    const bool wide = (b.Cout % 128 == 0);
+    const int th = wide ? 16 : 32, bn = wide ? 128 : 64;
+    int tiles = 0;
+    for (int i = 0; i < b.n; ++i) {
+        if ((size_t)b.img[i].H * b.img[i].W * b.Cin * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
+        b.img[i].tiles_x = (b.img[i].W + 15) / 16;
+        tiles += b.img[i].tiles_x * ((b.img[i].H + th - 1) / th);
+        b.img[i].tile_end = tiles;
+    }
+    const int blocks = tiles * (b.Cout / bn);
+    if (wide) {
+        constexpr int lds = BfCfg<16, 128>::LDS_BYTES;
+        hipLaunchKernelGGL((conv_bf3_batch_kernel<16, 128>), dim3(blocks), dim3(512), lds, stream, b);
+    } else {
+        constexpr int lds = BfCfg<32, 64>::LDS_BYTES;
+        hipLaunchKernelGGL((conv_bf3_batch_kernel<32, 64>), dim3(blocks), dim3(512), lds, stream, b);
+    }
+    return hipGetLastError();
 }
 
 // One workgroup per CU: cost(S) = rounds of workgroups over the 256 CUs x chunks per workgroup.  Split the

@@ -82,6 +82,7 @@ struct nst_ctx {
     void* wf_bf[NL] = {};       // the same weights cut into 3 bf16 pieces (conv_bf3.hip layout)
     void* wd_bf[NL] = {};
     int conv_bf3 = 1;           // 1: 3x3 convs on the bf16 pipe with 3-piece operands; 0: fp32 MFMA
+    int batched = 1;            // 1: one conv launch per layer covering every pyramid level (one stream)
     float* bias[NL] = {};
     float* w11k = nullptr;      // [28][64]
     float* w11d = nullptr;      // [9][64][4]
@@ -406,6 +407,131 @@ size_t gram_part_floats_for(int h, int w) {
     return mx;
 }
 
+// ---- closure with every conv layer launched once for all pyramid levels ("batched") ----------------------
+// Layer l has the same weights and channel counts at every level, and layer l of any level depends only on
+// layer l-1 of that level, so the 12 forward and 12 input-gradient convolutions each become ONE launch whose
+// grid lists the tiles of level 0, then level 1, ...: the small levels fill the tail of the big level's grid
+// instead of running as under-filled launches.  Everything is ordered on the caller's stream.
+int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsigned level_mask, float cw, float sw,
+                    float tvw, hipStream_t s) {
+    int lv[NST_MAX_LEVELS], n = 0;
+    for (int i = 0; i < ctx->levels; ++i) {
+        if ((level_mask >> i) & 1u) lv[n++] = i;
+        else HIPCHK(ctx, hipMemsetAsync(gi[i], 0, (size_t)3 * ctx->lv[i].h * ctx->lv[i].w * sizeof(float), s));
+    }
+    if (n == 0) return NST_OK;
+    // ---- forward
+    for (int k = 0; k < n; ++k) {
+        LevelWs& L = ctx->lv[lv[k]];
+        ActSet& a = L.acts;
+        for (int l = 0; l < NL; ++l) a.bits_valid[l] = false;
+        for (int q = 0; q < 4; ++q) a.pooled[q] = false;
+        {
+            Timer t(ctx, s, K_OTHER, 0);
+            HIPCHK(ctx, launch_tv_partial(xi[lv[k]], 3, L.h, L.w, L.tv_partial, s));
+        }
+        Timer t(ctx, s, K_CONV1, conv_flops(L.h, L.w, 3, 64, 9));
+        HIPCHK(ctx, launch_conv1_1_fwd(xi[lv[k]], L.h, L.w, ctx->w11k, ctx->bias[0], a.act[0], a.bits[0], s));
+        a.bits_valid[0] = true;
+    }
+    for (int l = 1; l < NL; ++l) {
+        const int pk = pool_index_after(l - 1), pa = pool_index_after(l);
+        ConvBatch b{};
+        b.n = n; b.wt_bf = ctx->wf_bf[l]; b.bias = ctx->bias[l]; b.Cin = kCin[l]; b.Cout = kCout[l]; b.relu = 1;
+        double flops = 0;
+        for (int k = 0; k < n; ++k) {
+            ActSet& a = ctx->lv[lv[k]].acts;
+            ConvImage& im = b.img[k];
+            im.in = (pk >= 0) ? a.pool[pk] : a.act[l - 1];
+            im.out = a.act[l]; im.H = a.h[l]; im.W = a.w[l];
+            im.bits_out = a.bits[l];
+            im.pool_out = (pa >= 0) ? a.pool[pa] : nullptr;
+            a.bits_valid[l] = a.bits[l] != nullptr;
+            if (pa >= 0) a.pooled[pa] = true;
+            flops += conv_flops(im.H, im.W, b.Cin, b.Cout, 9);
+        }
+        Timer t(ctx, s, K_CONV3, flops, b.img[0].H, b.img[0].W, b.Cin, b.Cout, 9, l);
+        HIPCHK(ctx, launch_conv_bf3_batch(b, s));
+    }
+    // ---- style losses: Gram matrices, S = d loss / d G folded for the backward
+    for (int k = 0; k < n; ++k) {
+        LevelWs& L = ctx->lv[lv[k]];
+        for (int q = 0; q < 5; ++q) {
+            const int l = kStyleLayer[q];
+            const int C = kCout[l];
+            const size_t N = (size_t)L.acts.h[l] * L.acts.w[l];
+            const double chw = (double)C * (double)N;
+            const float coef = (float)((double)sw * 4.0 / (5.0 * (double)C * C * chw));
+            NSTCHK(gram_of(ctx, L.acts.act[l], N, C, (float)chw, L.gram_part, L.gram_t[q], coef, nullptr, L.S[q],
+                           L.S_bf[q], L.style_partial[q], s));
+        }
+    }
+    // ---- backward
+    float* cur[NST_MAX_LEVELS]; float* oth[NST_MAX_LEVELS];
+    for (int k = 0; k < n; ++k) {
+        LevelWs& L = ctx->lv[lv[k]];
+        ActSet& a = L.acts;
+        cur[k] = L.gbuf[0]; oth[k] = L.gbuf[1];
+        const int l = NL - 1;
+        ConvParams p{};
+        p.in = a.act[l]; p.wt = L.S[4]; p.out = cur[k]; p.mask = a.act[l];
+        p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCout[l]; p.Cout = kCout[l];
+        Timer t(ctx, s, K_GRAM, conv_flops(p.H, p.W, p.Cin, p.Cout, 1));
+        HIPCHK(ctx, launch_conv_mfma(p, 1, s));
+    }
+    for (int l = NL - 1; l >= 1; --l) {
+        const int pk = pool_index_after(l - 1);
+        const int m = l - 1;
+        int style_q = -1;
+        for (int q = 0; q < 5; ++q) if (kStyleLayer[q] == m) style_q = q;
+        ConvBatch b{};
+        b.n = n; b.wt_bf = ctx->wd_bf[l]; b.bias = nullptr; b.Cin = kCout[l]; b.Cout = kCin[l]; b.relu = 0;
+        b.Cin2 = (pk < 0 && style_q >= 0) ? kCout[m] : 0;
+        double flops = 0;
+        for (int k = 0; k < n; ++k) {
+            LevelWs& L = ctx->lv[lv[k]];
+            ActSet& a = L.acts;
+            ConvImage& im = b.img[k];
+            im.in = cur[k]; im.out = oth[k]; im.H = a.h[l]; im.W = a.w[l];
+            flops += conv_flops(im.H, im.W, b.Cin, b.Cout, 9);
+            if (pk >= 0) continue;
+            if (style_q >= 0) {
+                im.in2 = a.act[m]; im.wt2_bf = L.S_bf[style_q];
+                flops += conv_flops(a.h[m], a.w[m], kCout[m], kCout[m], 1);
+            } else if (m == kContentLayer) {
+                Timer t(ctx, s, K_OTHER, 0);
+                HIPCHK(ctx, launch_mse_grad(a.act[m], L.content_t, L.content_n,
+                                            (float)((double)cw * 2.0 / (double)L.content_n), oth[k], L.content_partial, s));
+                im.addend = oth[k];
+            }
+            im.bits_in = a.bits[m];
+        }
+        {
+            Timer t(ctx, s, K_CONV3, flops, b.img[0].H, b.img[0].W, b.Cin, b.Cout, 9, -l);
+            HIPCHK(ctx, launch_conv_bf3_batch(b, s));
+        }
+        for (int k = 0; k < n; ++k) {
+            ActSet& a = ctx->lv[lv[k]].acts;
+            if (pk >= 0) {
+                Timer t(ctx, s, K_OTHER, 0);
+                HIPCHK(ctx, launch_maxpool_bwd_relu(a.act[l - 1], oth[k], a.h[l - 1], a.w[l - 1], kCout[l - 1], cur[k], s));
+            } else {
+                float* tmp = cur[k]; cur[k] = oth[k]; oth[k] = tmp;
+            }
+        }
+    }
+    for (int k = 0; k < n; ++k) {
+        LevelWs& L = ctx->lv[lv[k]];
+        {
+            Timer t(ctx, s, K_CONV1, conv_flops(L.h, L.w, 64, 3, 9));
+            HIPCHK(ctx, launch_conv1_1_dgrad(cur[k], L.h, L.w, ctx->w11d, gi[lv[k]], s));
+        }
+        Timer t(ctx, s, K_OTHER, 0);
+        HIPCHK(ctx, launch_tv_finish(xi[lv[k]], 3, L.h, L.w, L.tv_partial, tvw, gi[lv[k]], 1, L.tv_means, s));
+    }
+    return NST_OK;
+}
+
 void free_level(nst_ctx* ctx, LevelWs& L) {
     free_acts(ctx, L.acts);
     dev_free(L.gbuf[0]); dev_free(L.gbuf[1]); dev_free(L.xl); dev_free(L.gxl); dev_free(L.content_t);
@@ -479,6 +605,8 @@ int nst_ctx_create(int device, const float* const* weights, const float* const* 
     if (e == hipSuccess) e = gram_init_device();
     const char* cm = getenv("NST_CONV");
     if (cm && std::strcmp(cm, "f32") == 0) ctx->conv_bf3 = 0;
+    const char* bm = getenv("NST_BATCH");
+    if (bm && bm[0] == '0') ctx->batched = 0;
     if (e != hipSuccess) { ctx->err = std::string("kernel attribute setup: ") + hipGetErrorString(e); return bail(NST_E_HIP); }
     const char* ss = getenv("NST_SINGLE_STREAM");
     ctx->single_stream = ss && ss[0] == '1';
@@ -675,10 +803,16 @@ int nst_closure_levels(nst_ctx* ctx, const float* x, float cw, float sw, float t
         HIPCHK(ctx, launch_bicubic_down(xi[i - 1], 3, ctx->lv[i - 1].h, ctx->lv[i - 1].w, L.h, L.w, L.xl, main));
         xi[i] = L.xl; gi[i] = L.gxl;
     }
-    const bool multi = !ctx->single_stream && ctx->levels > 1;
+    // batched path: needs the bf16 conv kernels (32-bit buffer offsets) and enough tiles to be worth it
+    bool batch = ctx->batched && ctx->conv_bf3 && (size_t)ctx->lv[0].h * ctx->lv[0].w * 64 * 4 < 0xFFFFFF00ull &&
+                 (ctx->levels > 1 || (size_t)ctx->lv[0].h * ctx->lv[0].w >= (size_t)256 * 256);
+    if (batch) {
+        NSTCHK(closure_batched(ctx, xi, gi, level_mask, cw, sw, tvw, main));
+    }
+    const bool multi = !batch && !ctx->single_stream && ctx->levels > 1;
     if (multi) HIPCHK(ctx, hipEventRecord(ctx->fork, main));
 
-    for (int i = 0; i < ctx->levels; ++i) {
+    for (int i = 0; i < ctx->levels && !batch; ++i) {
         LevelWs& L = ctx->lv[i];
         hipStream_t s = multi ? L.stream : main;
         if (multi) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->fork, 0));

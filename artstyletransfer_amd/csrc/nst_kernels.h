@@ -31,6 +31,28 @@ struct ConvParams {
     float* pool_out;      // optional: 2x2/2 max-pooled output [H/2][W/2][Cout]
 };
 
+// One image (pyramid level) of a batched conv_bf3 launch; the layer's weights / channel counts are shared.
+struct ConvImage {
+    const float* in;
+    const float* addend;
+    const float* mask;
+    float* out;
+    const float* in2;
+    const void* wt2_bf;
+    unsigned* bits_out;
+    const unsigned* bits_in;
+    float* pool_out;
+    int H, W;
+    int tiles_x, tile_end;   // filled by the launcher
+};
+struct ConvBatch {
+    ConvImage img[8];
+    int n;
+    const void* wt_bf;
+    const float* bias;
+    int Cin, Cout, Cin2, relu;
+};
+
 // conv_mfma.hip
 hipError_t conv_mfma_init_device();
 hipError_t launch_conv_mfma(const ConvParams& p, int taps, hipStream_t stream);
@@ -42,6 +64,7 @@ hipError_t launch_conv_splitk_finish(const ConvParams& p, hipStream_t stream);
 // conv_bf3.hip: the same 3x3 convolution on the bf16 matrix pipe with 3-piece operands (fp32-level accuracy)
 hipError_t conv_bf3_init_device();
 hipError_t launch_conv_bf3(const ConvParams& p, hipStream_t stream);
+hipError_t launch_conv_bf3_batch(const ConvBatch& b, hipStream_t stream);
 int conv_bf3_ksplit(int H, int W, int Cin, int Cout);
 
 // conv_first.hip: conv1_1 (3 -> 64) forward from the planar image, and its input gradient
