@@ -261,8 +261,8 @@ def main():
             out["kernel_ms_per_closure"] = {
                 "closure": cms / max(cn, 1), "conv3x3_mfma": ms / max(cn, 1), "gram_mfma": gms / max(cn, 1),
                 "conv1_1": c1ms / max(cn, 1), "streaming": oms / max(cn, 1)}
-            if world == 1 and not os.environ.get("NST_SINGLE_STREAM"):
-                # Under the default schedule the pyramid levels run on separate HIP streams, so the launch durations
+            if world == 1 and os.environ.get("NST_BATCH") == "0" and not os.environ.get("NST_SINGLE_STREAM"):
+                # Under the NST_BATCH=0 schedule the pyramid levels run on separate HIP streams, so the launch durations
                 # above are taken while kernels of other levels share the CUs (their sum exceeds the closure time).
                 # The same closures re-run on ONE stream give each kernel's duration with the chip to itself.
                 out["roofline"]["note"] = ("launch durations measured while kernels of the other pyramid levels run "

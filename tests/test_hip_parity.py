@@ -241,6 +241,29 @@ def test_closure_vs_oracle(eng, vgg_weights, golden, h, w, nlev, hs, ws):
         assert float((g0.double() ** 2).sum().cpu()) == pytest.approx(float(fx["grad.sq_sum"]), rel=1e-4)
 
 
+@pytest.mark.parametrize("env", [{"NST_CONV": "f32"}, {"NST_BATCH": "0"}, {"NST_BATCH": "0", "NST_SINGLE_STREAM": "1"},
+                                 {"NST_CONV": "f32", "NST_BATCH": "0"}])
+def test_closure_execution_modes_agree(eng, vgg_weights, monkeypatch, env):
+    """The alternative schedules / arithmetic (fp32-MFMA convs; one launch per level on per-level streams or on one
+    stream) must give the default path's closure (bf16x3 convs, one launch per layer over all levels)."""
+    from artstyletransfer_amd.engine import StyleEngine
+    c, s = _levels(128, 192, 3, 1), _levels(96, 160, 3, 2)
+    x = dev(cpu_ref.prepare_img((0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(128, 192, seed=9)).astype(np.float32)))
+    _setup(eng, c, s)
+    g0, l0 = eng.closure(x, 1e3, 4e5, 1e2)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    other = StyleEngine(vgg_weights, 0)
+    try:
+        assert other.conv_mode() == ("f32" if env.get("NST_CONV") == "f32" else "bf16x3")
+        _setup(other, c, s)
+        g1, l1 = other.closure(x, 1e3, 4e5, 1e2)
+        np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=1e-5, atol=1e-7)
+        assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < GRAD_RTOL
+    finally:
+        other.close()
+
+
 def test_closure_finite_difference(eng, vgg_weights):
     """Directional derivative of the HIP loss against its own gradient (size-independent property)."""
     c, s = _levels(64, 96, 2, 1), _levels(64, 96, 2, 2)
