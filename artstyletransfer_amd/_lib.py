@@ -10,7 +10,7 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnst_hip.so")
+LIB_PATH = os.environ.get("NST_LIB") or os.path.join(_HERE, "libnst_hip.so")   # NST_LIB: experiment builds
 CSRC = os.path.join(_HERE, "csrc")
 
 NST_OK = 0

@@ -16,6 +16,7 @@
 // = 13 x 16 B: 16 consecutive rows start on 16 distinct 16-B slots -> conflict-free ds_read_b128 fragments.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "nst_kernels.h"
@@ -34,7 +35,11 @@ constexpr int KC = 32;            // channels per chunk
 constexpr int ROWB = 208;         // LDS row bytes: 3 pieces x 64 B + 16 B pad
 constexpr int WROWB = 192;        // global weight row bytes per (tap, cout, chunk): 3 pieces x 32 bf16
 
-template <int TH, int BN>
+// NBUF = 2: one 512-thread workgroup per CU, weight slices double buffered (one barrier per stage).
+// NBUF = 1: 256-thread workgroups small enough (65 KB LDS) for TWO per CU; the weight slice is single
+//           buffered (two barriers per stage), and the stalls of one workgroup - stage boundaries, halo-patch
+//           refills, prologue, epilogue - are covered by the other workgroup's MFMAs on the same SIMDs.
+template <int TH, int BN, int NBUF>
 struct BfCfg {
     static constexpr int TW = 16;
     static constexpr int PH = TH + 2, PW = TW + 2;
@@ -50,8 +55,8 @@ struct BfCfg {
     static constexpr int PROWB = ((PW * ROWB + 255) / 256) * 256;
     static constexpr int A_BYTES = PH * PROWB;
     static constexpr int B_BYTES = BN * ROWB;
-    static constexpr int LDS_BYTES = A_BYTES + 2 * B_BYTES;
-    static_assert(NT == 512, "eight waves per workgroup");
+    static constexpr int LDS_BYTES = A_BYTES + NBUF * B_BYTES;
+    static_assert(NT == 512 || NT == 256, "eight or four waves per workgroup");
     static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 };
 
@@ -71,9 +76,9 @@ __device__ __forceinline__ unsigned pack2(unsigned first, unsigned second) {
 }  // namespace
 
 // the whole workgroup program; (sp, ct, split) = spatial tile, output-channel tile, K split of this workgroup
-template <int TH, int BN>
+template <int TH, int BN, int NBUF>
 __device__ __forceinline__ void conv_bf3_body(const ConvParams& p, const int sp, const int ct, const int split) {
-    using C = BfCfg<TH, BN>;
+    using C = BfCfg<TH, BN, NBUF>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ldsA = smem;
     unsigned char* ldsB = smem + C::A_BYTES;
@@ -202,6 +207,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvParams& p, const int sp,
             store_a();
 #pragma unroll
             for (int t = 0; t < NTAPS; ++t) {
+                if (NBUF == 1 && t > 0) __syncthreads();     // single weight buffer: everyone is done reading it
                 store_b(cur);
                 __syncthreads();
                 if (t + 1 < NTAPS) {
@@ -252,7 +258,7 @@ __device__ __forceinline__ void conv_bf3_body(const ConvParams& p, const int sp,
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
                 __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);
-                cur ^= 1;
+                if (NBUF == 2) cur ^= 1;
             }
         }
     };
@@ -333,18 +339,18 @@ __device__ __forceinline__ void conv_bf3_body(const ConvParams& p, const int sp,
     }
 }
 
-template <int TH, int BN>
-__global__ __launch_bounds__(512) void conv_bf3_kernel(ConvParams p) {
+template <int TH, int BN, int NBUF>
+__global__ __launch_bounds__(512, 2) void conv_bf3_kernel(ConvParams p) {
     const int n_ct = p.Cout / BN;
-    conv_bf3_body<TH, BN>(p, blockIdx.x / n_ct, blockIdx.x % n_ct, blockIdx.y);
+    conv_bf3_body<TH, BN, NBUF>(p, blockIdx.x / n_ct, blockIdx.x % n_ct, blockIdx.y);
 }
 
 // One launch = one layer over several images (the pyramid levels of a closure): same weights, same channel
 // counts, each image with its own tensors and size.  Workgroups are numbered image by image, so the few
 // tiles of the small levels fill the tail of the big level's grid instead of running as under-filled
 // launches of their own.
-template <int TH, int BN>
-__global__ __launch_bounds__(512) void conv_bf3_batch_kernel(ConvBatch b) {
+template <int TH, int BN, int NBUF>
+__global__ __launch_bounds__(512, 2) void conv_bf3_batch_kernel(ConvBatch b) {
     const int n_ct = b.Cout / BN;
     const int sp_all = blockIdx.x / n_ct;
     int i = 0;
@@ -356,31 +362,52 @@ __global__ __launch_bounds__(512) void conv_bf3_batch_kernel(ConvBatch b) {
     p.tiles_x = im.tiles_x; p.tiles_y = 0; p.partial = nullptr; p.partial_floats = 0; p.ksplit = 1;
     p.in2 = im.in2; p.Cin2 = b.Cin2; p.wt2_bf = im.wt2_bf; p.bits_out = im.bits_out; p.bits_in = im.bits_in;
     p.pool_out = im.pool_out;
-    conv_bf3_body<TH, BN>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), blockIdx.x % n_ct, 0);
+    conv_bf3_body<TH, BN, NBUF>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), blockIdx.x % n_ct, 0);
+}
+
+template <int TH, int BN, int NBUF>
+static hipError_t init_one() {
+    constexpr int lds = BfCfg<TH, BN, NBUF>::LDS_BYTES;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<TH, BN, NBUF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_batch_kernel<TH, BN, NBUF>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 hipError_t conv_bf3_init_device() {
-    constexpr int lds_w = BfCfg<16, 128>::LDS_BYTES, lds_n = BfCfg<32, 64>::LDS_BYTES;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<16, 128>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds_w);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_kernel<32, 64>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_n);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_batch_kernel<16, 128>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_w);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf3_batch_kernel<32, 64>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_n);
+    hipError_t e = init_one<16, 128, 2>();
+    if (e == hipSuccess) e = init_one<8, 128, 1>();
+    if (e == hipSuccess) e = init_one<32, 64, 2>();
     return e;
 }
 
-// fills tiles_x / tile_end of every image; returns the number of workgroups
+// tile choice for the 128-wide layers: two 256-thread workgroups per CU (default) or one 512-thread one
+static bool small_tiles() {
+    static const int v = [] { const char* e = getenv("NST_BF3_TILE"); return (e && e[0] == 'b') ? 0 : 1; }();
+    return v != 0;
+}
+static int tile_rows(int Cout) { return (Cout % 128 == 0) ? (small_tiles() ? 8 : 16) : 32; }
+
+template <int TH, int BN, int NBUF>
+static void launch_batch_cfg(const ConvBatch& b, int blocks, hipStream_t stream) {
+    constexpr int lds = BfCfg<TH, BN, NBUF>::LDS_BYTES;
+    constexpr int nt = BfCfg<TH, BN, NBUF>::NT;
+    hipLaunchKernelGGL((conv_bf3_batch_kernel<TH, BN, NBUF>), dim3(blocks), dim3(nt), lds, stream, b);
+}
+template <int TH, int BN, int NBUF>
+static void launch_single_cfg(const ConvParams& p, int blocks, hipStream_t stream) {
+    constexpr int lds = BfCfg<TH, BN, NBUF>::LDS_BYTES;
+    constexpr int nt = BfCfg<TH, BN, NBUF>::NT;
+    hipLaunchKernelGGL((conv_bf3_kernel<TH, BN, NBUF>), dim3(blocks, p.ksplit), dim3(nt), lds, stream, p);
+}
+
+// fills tiles_x / tile_end of every image and launches one grid over all of them
 hipError_t launch_conv_bf3_batch(const ConvBatch& b0, hipStream_t stream) {
     if (b0.n < 1 || b0.n > 8 || b0.Cin % 32 != 0 || b0.Cout % 64 != 0 || !b0.wt_bf) return hipErrorInvalidValue;
     ConvBatch b = b0;
     const bool wide = (b.Cout % 128 == 0);
-    const int th = wide ? 16 : 32, bn = wide ? 128 : 64;
+    const int th = tile_rows(b.Cout), bn = wide ? 128 : 64;
     int tiles = 0;
     for (int i = 0; i < b.n; ++i) {
         if ((size_t)b.img[i].H * b.img[i].W * b.Cin * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
@@ -389,26 +416,23 @@ hipError_t launch_conv_bf3_batch(const ConvBatch& b0, hipStream_t stream) {
         b.img[i].tile_end = tiles;
     }
     const int blocks = tiles * (b.Cout / bn);
-    if (wide) {
-        constexpr int lds = BfCfg<16, 128>::LDS_BYTES;
-        hipLaunchKernelGGL((conv_bf3_batch_kernel<16, 128>), dim3(blocks), dim3(512), lds, stream, b);
-    } else {
-        constexpr int lds = BfCfg<32, 64>::LDS_BYTES;
-        hipLaunchKernelGGL((conv_bf3_batch_kernel<32, 64>), dim3(blocks), dim3(512), lds, stream, b);
-    }
+    if (!wide) launch_batch_cfg<32, 64, 2>(b, blocks, stream);
+    else if (th == 8) launch_batch_cfg<8, 128, 1>(b, blocks, stream);
+    else launch_batch_cfg<16, 128, 2>(b, blocks, stream);
     return hipGetLastError();
 }
 
-// One workgroup per CU: cost(S) = rounds of workgroups over the 256 CUs x chunks per workgroup.  Split the
-// channel chunks when that removes a partly filled round (e.g. 384 tiles: 2 rounds of 16 chunks -> 3 rounds
-// of 8); the ordered finish pass costs one extra read of S partial maps, so a split must save >= 12 %.
+// cost(S) = rounds of workgroups over the CU slots x chunks per workgroup.  Split the channel chunks when that
+// removes a partly filled round (e.g. 384 tiles on 256 slots: 2 rounds of 16 chunks -> 3 rounds of 8); the
+// ordered finish pass costs one extra read of S partial maps, so a split must save >= 12 %.
 int conv_bf3_ksplit(int H, int W, int Cin, int Cout) {
     const bool wide = (Cout % 128 == 0);
-    const int th = wide ? 16 : 32, bn = wide ? 128 : 64;
+    const int th = tile_rows(Cout), bn = wide ? 128 : 64;
+    const long slots = (wide && th == 8) ? 512 : 256;
     const long blocks = (long)((H + th - 1) / th) * ((W + 15) / 16) * (Cout / bn);
     const int nchunks = Cin / 32;
     if (nchunks < 2) return 1;
-    auto cost = [&](int S) { return (double)((blocks * S + 255) / 256) * (nchunks / S); };
+    auto cost = [&](int S) { return (double)((blocks * S + slots - 1) / slots) * (nchunks / S); };
     double best = cost(1);
     for (int S = 2; S <= nchunks && S <= 16; S *= 2)
         if (nchunks % S == 0 && cost(S) < best) best = cost(S);
@@ -430,18 +454,13 @@ hipError_t launch_conv_bf3(const ConvParams& p0, hipStream_t stream) {
         if (S > 1 && (size_t)S * p.H * p.W * p.Cout <= p.partial_floats) p.ksplit = S;
     }
     const bool wide = (p.Cout % 128 == 0);
+    const int th = tile_rows(p.Cout), bn = wide ? 128 : 64;
     p.tiles_x = (p.W + 15) / 16;
-    if (wide) {
-        p.tiles_y = (p.H + 15) / 16;
-        const int blocks = p.tiles_x * p.tiles_y * (p.Cout / 128);
-        constexpr int lds = BfCfg<16, 128>::LDS_BYTES;
-        hipLaunchKernelGGL((conv_bf3_kernel<16, 128>), dim3(blocks, p.ksplit), dim3(512), lds, stream, p);
-    } else {
-        p.tiles_y = (p.H + 31) / 32;
-        const int blocks = p.tiles_x * p.tiles_y * (p.Cout / 64);
-        constexpr int lds = BfCfg<32, 64>::LDS_BYTES;
-        hipLaunchKernelGGL((conv_bf3_kernel<32, 64>), dim3(blocks, p.ksplit), dim3(512), lds, stream, p);
-    }
+    p.tiles_y = (p.H + th - 1) / th;
+    const int blocks = p.tiles_x * p.tiles_y * (p.Cout / bn);
+    if (!wide) launch_single_cfg<32, 64, 2>(p, blocks, stream);
+    else if (th == 8) launch_single_cfg<8, 128, 1>(p, blocks, stream);
+    else launch_single_cfg<16, 128, 2>(p, blocks, stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || p.ksplit == 1) return e;
     return launch_conv_splitk_finish(p, stream);
