@@ -382,12 +382,22 @@ hipError_t conv_bf3_init_device() {
     return e;
 }
 
-// tile choice for the 128-wide layers: two 256-thread workgroups per CU (default) or one 512-thread one
+// tile choice for the 128-wide layers: one 512-thread workgroup per CU (default) or two 256-thread ones
+// (NST_BF3_TILE=small; measured equal: the kernel is clock/power bound, not stall bound)
 static bool small_tiles() {
-    static const int v = [] { const char* e = getenv("NST_BF3_TILE"); return (e && e[0] == 'b') ? 0 : 1; }();
+    static const int v = [] { const char* e = getenv("NST_BF3_TILE"); return (e && e[0] == 's') ? 1 : 0; }();
     return v != 0;
 }
 static int tile_rows(int Cout) { return (Cout % 128 == 0) ? (small_tiles() ? 8 : 16) : 32; }
+// a launch whose 512-thread tiles cannot fill 256 CUs twice over uses the 256-thread tile (twice as many
+// workgroups, two per CU): conv5_1 of the whole pyramid is 54 big tiles x 4 channel tiles
+static int batch_tile_rows(const ConvBatch& b) {
+    int th = tile_rows(b.Cout);
+    if (th != 16) return th;
+    long blocks = 0;
+    for (int i = 0; i < b.n; ++i) blocks += (long)((b.img[i].H + 15) / 16) * ((b.img[i].W + 15) / 16) * (b.Cout / 128);
+    return blocks < 400 ? 8 : 16;
+}
 
 template <int TH, int BN, int NBUF>
 static void launch_batch_cfg(const ConvBatch& b, int blocks, hipStream_t stream) {
@@ -407,7 +417,7 @@ hipError_t launch_conv_bf3_batch(const ConvBatch& b0, hipStream_t stream) {
     if (b0.n < 1 || b0.n > 8 || b0.Cin % 32 != 0 || b0.Cout % 64 != 0 || !b0.wt_bf) return hipErrorInvalidValue;
     ConvBatch b = b0;
     const bool wide = (b.Cout % 128 == 0);
-    const int th = tile_rows(b.Cout), bn = wide ? 128 : 64;
+    const int th = batch_tile_rows(b), bn = wide ? 128 : 64;
     int tiles = 0;
     for (int i = 0; i < b.n; ++i) {
         if ((size_t)b.img[i].H * b.img[i].W * b.Cin * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
