@@ -54,6 +54,12 @@ SYMBOLS = {
     "nst_bicubic_half_backward": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void]),
     "nst_prepare_img": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void, c_void]),
     "nst_unprepare_img": (C.c_int, [c_void, c_void, C.c_int, C.c_int, c_void, c_void]),
+    "nst_resize_bicubic": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, C.c_int, C.c_int, c_void]),
+    "nst_gather_rows": (C.c_int, [c_void, c_void, c_void, C.c_size_t, C.c_int, c_void, c_void]),
+    "nst_gaussian_mask_accumulate": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double,
+                                               C.c_double, c_void]),
+    "nst_noise_blend": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_double, c_void, c_void]),
+    "nst_scale": (C.c_int, [c_void, c_void, C.c_float, C.c_size_t, c_void, c_void]),
     "nst_conv_mode": (C.c_int, [c_void]),
     "nst_ctx_bytes": (C.c_int, [c_void, C.POINTER(C.c_size_t)]),
     "nst_set_timing": (C.c_int, [c_void, C.c_int]),

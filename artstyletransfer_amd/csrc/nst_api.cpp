@@ -1098,6 +1098,55 @@ int nst_unprepare_img(nst_ctx* ctx, const float* chw, int h, int w, float* hwc, 
     return NST_OK;
 }
 
+// ---- job set-up on the device -------------------------------------------------
+int nst_resize_bicubic(nst_ctx* ctx, const float* src, int h, int w, int channels, float* dst, int nh, int nw, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!src || !dst || h < 1 || w < 1 || nh < 1 || nw < 1 || channels < 1) return fail(ctx, NST_E_ARG, "bad argument");
+    HIPCHK(ctx, launch_resize_hwc(src, h, w, channels, dst, nh, nw, static_cast<hipStream_t>(stream)));
+    return NST_OK;
+}
+int nst_gather_rows(nst_ctx* ctx, const float* src, const long long* perm, size_t rows, int channels, float* dst, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!src || !perm || !dst || channels < 1) return fail(ctx, NST_E_ARG, "bad argument");
+    HIPCHK(ctx, launch_gather_rows(src, perm, rows, channels, dst, static_cast<hipStream_t>(stream)));
+    return NST_OK;
+}
+int nst_gaussian_mask_accumulate(nst_ctx* ctx, float* acc, const float* src, int h, int w, int channels, double central,
+                                 double peripheral, double dispersion, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!acc || h < 1 || w < 1 || channels < 1) return fail(ctx, NST_E_ARG, "bad argument");
+    HIPCHK(ctx, launch_gauss_mask_acc(acc, src, h, w, channels, central, peripheral, dispersion, static_cast<hipStream_t>(stream)));
+    return NST_OK;
+}
+int nst_noise_blend(nst_ctx* ctx, const float* content, const float* noise, int h, int w, int channels, double noise_factor,
+                    float* out, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!content || !noise || !out || h < 1 || w < 1 || channels < 1) return fail(ctx, NST_E_ARG, "bad argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t n = (size_t)h * w * channels;
+    double* t0 = nullptr; double* t1 = nullptr; double* wt = nullptr;
+    int r = dev_alloc_t(ctx, &t0, n);
+    if (r == NST_OK) r = dev_alloc_t(ctx, &t1, n);
+    if (r == NST_OK) r = dev_alloc_t(ctx, &wt, n);
+    hipError_t e = hipSuccess;
+    if (r == NST_OK) {
+        e = launch_blend_weight(content, h, w, channels, noise_factor, t0, t1, wt, s);
+        if (e == hipSuccess) e = launch_blend_init(content, noise, wt, n, out, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    }
+    dev_free(t0); dev_free(t1); dev_free(wt);
+    if (ctx->bytes >= 3 * n * 8) ctx->bytes -= 3 * n * 8;
+    if (r != NST_OK) return r;
+    HIPCHK(ctx, e);
+    return NST_OK;
+}
+int nst_scale(nst_ctx* ctx, const float* src, float alpha, size_t n, float* dst, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!src || !dst) return fail(ctx, NST_E_ARG, "null argument");
+    HIPCHK(ctx, launch_scale(src, alpha, n, dst, static_cast<hipStream_t>(stream)));
+    return NST_OK;
+}
+
 // ---- internal accessors for nst_opt.cpp (not part of the public ABI) --------------------------------
 int nst_internal_device(const nst_ctx* ctx) { return ctx ? ctx->device : 0; }
 int nst_internal_levels(const nst_ctx* ctx) { return ctx ? ctx->levels : 0; }

@@ -144,6 +144,18 @@ int gram_finish_blocks(int C);
 hipError_t launch_gram_finish(const float* part, int nslabs, int C, float divisor, const float* target, float coef,
                               float* gram_out, float* S, unsigned short* S_bf, double* mse_partial, hipStream_t stream);
 
+// image_ops.hip: job set-up on the device (pyramid resize, structured-noise initial image) ---------------------
+hipError_t launch_resize_hwc(const float* src, int h, int w, int C, float* dst, int oh, int ow, hipStream_t stream);
+hipError_t launch_gather_rows(const float* src, const long long* perm, size_t n, int C, float* dst, hipStream_t stream);
+hipError_t launch_gauss_mask_acc(float* acc, const float* src, int h, int w, int C, double central, double peripheral,
+                                 double disp, hipStream_t stream);
+// weight (double, h*w*C) = 5 nf / (5 + blur(clip(|sobel5(content)|, 0, 100))); tmp0/tmp1: h*w*C doubles each
+hipError_t launch_blend_weight(const float* content, int h, int w, int C, double noise_factor, double* tmp0, double* tmp1,
+                               double* weight, hipStream_t stream);
+hipError_t launch_blend_init(const float* content, const float* noise, const double* weight, size_t n, float* out,
+                             hipStream_t stream);
+hipError_t launch_scale(const float* src, float alpha, size_t n, float* dst, hipStream_t stream);
+
 // vector_ops.hip: optimiser arithmetic over the n pixel floats ---------------------------------------
 constexpr int RED_BLOCKS = 256;
 // out[0] = sum(a*b) as float (double accumulation inside), deterministic two-stage

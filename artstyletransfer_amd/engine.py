@@ -222,6 +222,51 @@ class StyleEngine:
         return out
 
 
+    # ---- job set-up on the device -------------------------------------
+    def resize(self, img: torch.Tensor, nh: int, nw: int) -> torch.Tensor:
+        """cv2.INTER_CUBIC resize of an (h,w,c) float32 device image."""
+        _chk_dev(img, self.device)
+        h, w, c = img.shape
+        out = torch.empty((nh, nw, c), dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_resize_bicubic(self.ctx, _ptr(img), h, w, c, _ptr(out), nh, nw,
+                                                         _stream(self.device)), "nst_resize_bicubic")
+        return out
+
+    def gather_rows(self, src: torch.Tensor, perm: torch.Tensor) -> torch.Tensor:
+        _chk_dev(src, self.device)
+        assert perm.dtype == torch.int64 and perm.is_cuda and perm.is_contiguous()
+        out = torch.empty_like(src)
+        _lib.check(self.ctx, self.lib.nst_gather_rows(self.ctx, _ptr(src), _ptr(perm), perm.numel(), src.shape[-1],
+                                                      _ptr(out), _stream(self.device)), "nst_gather_rows")
+        return out
+
+    def gaussian_mask_accumulate(self, acc: torch.Tensor, src: Optional[torch.Tensor], central: float,
+                                 peripheral: float, dispersion: float) -> None:
+        _chk_dev(acc, self.device)
+        h, w, c = acc.shape
+        if src is not None:
+            _chk_dev(src, self.device, acc.shape)
+        _lib.check(self.ctx, self.lib.nst_gaussian_mask_accumulate(self.ctx, _ptr(acc), _ptr(src), h, w, c, central,
+                                                                   peripheral, dispersion, _stream(self.device)),
+                   "nst_gaussian_mask_accumulate")
+
+    def noise_blend(self, content: torch.Tensor, noise: torch.Tensor, noise_factor: float) -> torch.Tensor:
+        _chk_dev(content, self.device)
+        _chk_dev(noise, self.device, content.shape)
+        h, w, c = content.shape
+        out = torch.empty_like(content)
+        _lib.check(self.ctx, self.lib.nst_noise_blend(self.ctx, _ptr(content), _ptr(noise), h, w, c, noise_factor,
+                                                      _ptr(out), _stream(self.device)), "nst_noise_blend")
+        return out
+
+    def scale(self, src: torch.Tensor, alpha: float) -> torch.Tensor:
+        _chk_dev(src, self.device)
+        out = torch.empty_like(src)
+        _lib.check(self.ctx, self.lib.nst_scale(self.ctx, _ptr(src), alpha, src.numel(), _ptr(out),
+                                                _stream(self.device)), "nst_scale")
+        return out
+
+
 class PixelOptimizer:
     """nst_opt: torch.optim.Adam / LBFGS as the reference constructs them, driving the closure."""
 

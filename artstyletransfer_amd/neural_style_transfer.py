@@ -15,7 +15,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from . import host_image, math_utils
+from . import device_image, host_image, math_utils
 from .engine import PixelOptimizer, StyleEngine
 from .neural_nets import load_weights, shared_engine
 
@@ -112,11 +112,16 @@ class NeuralStyleTransfer:
         engine = StyleEngine(load_weights(), dev)
         try:
             engine.configure(len(content_imgs), h0, w0)
+            def prepared(img):      # numpy HWC (reference) or a device HWC tensor built by device_image
+                if isinstance(img, torch.Tensor):
+                    return engine.prepare_img(img.to(dev).contiguous())
+                return prepare_img(img, dev)
+
             for lvl, (c_img, s_img) in enumerate(zip(content_imgs, self.__style_imgs)):
                 if tuple(c_img.shape[:2]) != engine.level_shape(lvl):
-                    raise ValueError(f"content level {lvl} is {c_img.shape[:2]}, expected {engine.level_shape(lvl)}")
-                engine.set_targets(lvl, prepare_img(c_img, dev), prepare_img(s_img, dev))
-            optimizing_img = prepare_img(init_img, dev)
+                    raise ValueError(f"content level {lvl} is {tuple(c_img.shape[:2])}, expected {engine.level_shape(lvl)}")
+                engine.set_targets(lvl, prepared(c_img), prepared(s_img))
+            optimizing_img = prepared(init_img)
             optimizer = PixelOptimizer(engine, self.__optimizer_name, lr_start, LBFGS_MAX_EVAL)
             cw, sw, tvw = float(content_weight), float(style_weight), float(tv_weight)
             step = 0
@@ -194,15 +199,16 @@ async def neural_style_transfer(content_n_style: ContentStylePair,
         device = torch.device("cuda", torch.cuda.current_device())
     device = torch.device(device)
 
-    content_levels: List[np.ndarray] = []
-    style_levels: List[np.ndarray] = []
-    level = 0
-    for level in range(levels_num):
-        content_levels.insert(0, await resize(content_n_style.content[1], level=level))
-        style_levels.insert(0, await resize(content_n_style.style[1], level=level))
-
-    init_img, tag = host_image.initial_image(
-        init_method, content_n_style.content[1], content_n_style.style[1], content_levels[0], style_levels[0], level,
+    # pyramid + structured-noise initial image, on the device (device_image.py; host_image.py is the
+    # host restatement of the same algorithm)
+    setup = shared_engine(device)
+    content_dev = device_image.upload(setup, content_n_style.content[1])
+    style_dev = device_image.upload(setup, content_n_style.style[1])
+    content_levels = device_image.pyramid(setup, content_dev, levels_num)
+    style_levels = device_image.pyramid(setup, style_dev, levels_num)
+    level = max(levels_num - 1, 0)
+    init_img, tag = device_image.initial_image(
+        setup, init_method, content_dev, style_dev, content_levels[0], style_levels[0], level,
         noise_factor, noise_levels, noise_levels_central_amplitude, noise_levels_peripheral_amplitude,
         noise_levels_dispersion)
     init_name = {"random": "random", "content": content_n_style.content[0], "style": content_n_style.style[0]}[tag]

@@ -52,7 +52,10 @@ def mfma_roofline(mode, algorithmic_flops, ms, launches, extra=None):
 
 
 def build_job(levels_num: int, seed_shift: int, device):
-    from artstyletransfer_amd import host_image, synthetic
+    """Synthetic L = levels_num-1 job, set up the way neural_style_transfer() does it: pyramid and structured-noise
+    initial image on the device (device_image.py), targets through nst_level_set_targets."""
+    from artstyletransfer_amd import device_image, synthetic
+    from artstyletransfer_amd.config import Config
     from artstyletransfer_amd.engine import StyleEngine
 
     base_h, base_w = 256, 384
@@ -60,23 +63,26 @@ def build_job(levels_num: int, seed_shift: int, device):
     H, W = base_h << top, base_w << top
     content = synthetic.image(H, W, seed=1 + 2 * seed_shift)
     style = synthetic.image(H, W, seed=2 + 2 * seed_shift)
-    content_levels = [host_image.resize_to_level(content, l) for l in range(top, -1, -1)]
-    style_levels = [host_image.resize_to_level(style, l) for l in range(top, -1, -1)]
-    from artstyletransfer_amd.config import Config
     cfg = Config(levels_num=levels_num)
-    np.random.seed(0)
-    init, _ = host_image.initial_image(cfg.init_method, content, style, content_levels[0], style_levels[0], top,
-                                       cfg.noise_factor, cfg.noise_levels, cfg.noise_levels_central_amplitude,
-                                       cfg.noise_levels_peripheral_amplitude, cfg.noise_levels_dispersion)
     weights = synthetic.vgg19_weights()
     eng = StyleEngine(weights, device)
+    t0 = time.perf_counter()
+    cd, sd = device_image.upload(eng, content), device_image.upload(eng, style)
+    content_levels = device_image.pyramid(eng, cd, levels_num)
+    style_levels = device_image.pyramid(eng, sd, levels_num)
+    np.random.seed(0)
+    init, _ = device_image.initial_image(eng, cfg.init_method, cd, sd, content_levels[0], style_levels[0], top,
+                                         cfg.noise_factor, cfg.noise_levels, cfg.noise_levels_central_amplitude,
+                                         cfg.noise_levels_peripheral_amplitude, cfg.noise_levels_dispersion)
     eng.configure(levels_num, H, W)
     for l in range(levels_num):
-        c = eng.prepare_img(torch.from_numpy(content_levels[l]).to(eng.device))
-        s = eng.prepare_img(torch.from_numpy(style_levels[l]).to(eng.device))
-        eng.set_targets(l, c, s)
-    x = eng.prepare_img(torch.from_numpy(np.ascontiguousarray(init, dtype=np.float32)).to(eng.device))
-    return eng, x, cfg, (content_levels, style_levels, init, weights)
+        eng.set_targets(l, eng.prepare_img(content_levels[l]), eng.prepare_img(style_levels[l]))
+    x = eng.prepare_img(init)
+    torch.cuda.synchronize()
+    setup_ms = (time.perf_counter() - t0) * 1e3
+    host = ([t.cpu().numpy() for t in content_levels], [t.cpu().numpy() for t in style_levels], init.cpu().numpy(), weights)
+    cfg.job_setup_ms = setup_ms
+    return eng, x, cfg, host
 
 
 def cpu_baseline(job_host, cfg, closures: int):
@@ -250,7 +256,8 @@ def main():
                        "parallelism": ("1 GPU" if world == 1 else
                                        f"levels sharded over {world} ranks, RCCL all-reduce of the pixel gradient"
                                        if sharded else "1 job per GPU, no collective"),
-                       "final_loss": float(last_rows[-1][-1]) if last_rows is not None else None},
+                       "final_loss": float(last_rows[-1][-1]) if last_rows is not None else None,
+                       "job_setup_ms_on_device": round(getattr(cfg, "job_setup_ms", 0.0), 1)},
             "closure_tflops_algorithmic": closure_flops / 1e12,
             "closure_rate_tflops": closure_flops * (done / dt) / 1e12,
         }

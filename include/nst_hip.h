@@ -139,6 +139,26 @@ int nst_bicubic_half_backward(nst_ctx* ctx, const float* gy, int C, int h, int w
 int nst_prepare_img(nst_ctx* ctx, const float* hwc, int h, int w, float* chw, void* stream);
 int nst_unprepare_img(nst_ctx* ctx, const float* chw, int h, int w, float* hwc, void* stream);
 
+/* ---- job set-up on the device (the host-side OpenCV work of the reference's job driver) ----------- */
+
+/* cv2.resize(img, (nw, nh), interpolation=cv2.INTER_CUBIC) for float32 HWC images (bicubic, A = -0.75, half-pixel
+ * centres, replicate border, no antialias) - `resize` (neural_style_transfer.py:211-226) and the noise-map
+ * up-sampling (:304-305); src (h,w,channels) -> dst (nh,nw,channels), both on the device. */
+int nst_resize_bicubic(nst_ctx* ctx, const float* src, int h, int w, int channels, float* dst, int nh, int nw, void* stream);
+/* dst[i][:] = src[perm[i]][:]: the row shuffle of make_style_noise (:422-432) with the permutation drawn on the
+ * host by np.random.permutation (so the reference's RNG stream is reproduced); perm: device int64[rows]. */
+int nst_gather_rows(nst_ctx* ctx, const float* src, const long long* perm, size_t rows, int channels, float* dst, void* stream);
+/* acc += (src ? src : 1) * gaussian_mask((h,w), central, peripheral, dispersion) (gaussian_mask :396-418 and the
+ * accumulation at :283-284, :311-313); acc, src: device float32 (h,w,channels); mask evaluated in double. */
+int nst_gaussian_mask_accumulate(nst_ctx* ctx, float* acc, const float* src, int h, int w, int channels, double central,
+                                 double peripheral, double dispersion, void* stream);
+/* out = ((1 - nr) * content + nr * noise).astype(float32), nr = 5 nf / (5 + GaussianBlur_101,0.2(clip(|Sobel_5|, 0, 100)))
+ * computed in double (:331-343, :355-358); all (h,w,channels) device float32.  Synchronous. */
+int nst_noise_blend(nst_ctx* ctx, const float* content, const float* noise, int h, int w, int channels, double noise_factor,
+                    float* out, void* stream);
+/* dst = alpha * src (init_method 'random': 0.5 * noise, :351) */
+int nst_scale(nst_ctx* ctx, const float* src, float alpha, size_t n, float* dst, void* stream);
+
 /* arithmetic of the 3x3 convolutions: 1 = bf16 matrix pipe, both operands cut into three bf16 pieces that
  * sum to the fp32 value exactly, 6 MFMAs per product, fp32 accumulate (default; fp32-level error);
  * 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32; environment NST_CONV=f32 at context creation). */

@@ -398,6 +398,49 @@ def test_errors_are_reported(eng, vgg_weights):
         eng.closure(torch.zeros(1, 3, 32, 48, device="cuda:0"), 1.0, 1.0, 1.0)
 
 
+# ---------------------------------------------------------------- job set-up on the device (rows f-1 / f-2)
+@pytest.mark.parametrize("h,w,nh,nw", [(20, 30, 40, 60), (64, 96, 32, 48), (37, 53, 256, 367), (256, 383, 9, 13), (9, 13, 256, 384)])
+def test_device_resize_vs_host(eng, h, w, nh, nw):
+    from artstyletransfer_amd import host_image
+    img = np.random.RandomState(h + w).rand(h, w, 3).astype(np.float32)
+    ref = host_image.bicubic_resize(img, nh, nw)
+    out = eng.resize(dev(torch.from_numpy(img)), nh, nw).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6)
+
+
+def test_device_pyramid_and_noise_init_vs_host(eng):
+    """The whole job set-up of neural_style_transfer(): pyramid levels, multi-granularity style noise under
+    Gaussian envelopes (same numpy RNG stream), Sobel blend weight, initial image - device vs host restatement."""
+    from artstyletransfer_amd import config, device_image, host_image
+    cfg = config.Config()
+    content = cpu_ref.synthetic_image(150, 200, seed=1)
+    style = cpu_ref.synthetic_image(90, 140, seed=2)
+    levels = 2
+    c_host = [host_image.resize_to_level(content, l) for l in (1, 0)]
+    s_host = [host_image.resize_to_level(style, l) for l in (1, 0)]
+    cd, sd = device_image.upload(eng, content), device_image.upload(eng, style)
+    c_dev, s_dev = device_image.pyramid(eng, cd, levels), device_image.pyramid(eng, sd, levels)
+    for a, b in zip(c_dev + s_dev, c_host + s_host):
+        assert tuple(a.shape) == b.shape
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=2e-6)
+    args = (cfg.noise_factor, cfg.noise_levels, cfg.noise_levels_central_amplitude,
+            cfg.noise_levels_peripheral_amplitude, cfg.noise_levels_dispersion)
+    for method in ("content+noise", "random", "style"):
+        np.random.seed(7)
+        ref, tag_h = host_image.initial_image(method, content, style, c_host[0], s_host[0], 1, *args)
+        np.random.seed(7)
+        out, tag_d = device_image.initial_image(eng, method, cd, sd, c_dev[0], s_dev[0], 1, *args)
+        assert tag_h == tag_d and tuple(out.shape) == ref.shape
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=5e-6)
+    # the noise map alone, tall image (the other branch of the grid-size rule) and a single negative granularity
+    st = dev(torch.from_numpy(cpu_ref.synthetic_image(64, 48, seed=5)))
+    np.random.seed(3)
+    ref = host_image.noise_map(st.cpu().numpy(), (96, 64, 3), (5, -2, 0), (0.3, 0.2, 0.2), (0.2, 0.1, 0.0), (0.2, 0.6, 0.3))
+    np.random.seed(3)
+    out = device_image.noise_map(eng, st, (96, 64, 3), (5, -2, 0), (0.3, 0.2, 0.2), (0.2, 0.1, 0.0), (0.2, 0.6, 0.3))
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=5e-6)
+
+
 # ---------------------------------------------------------------- drop-in entry points, end to end
 def test_neural_style_transfer_generator_end_to_end(vgg_weights):
     """The reference's job API on the GPU: async generator yields (percent, HWC float32 image) per optimiser
