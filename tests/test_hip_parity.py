@@ -218,7 +218,9 @@ def _levels(h, w, nlev, seed):
     return out
 
 
-@pytest.mark.parametrize("h,w,nlev,hs,ws", [(128, 192, 3, 128, 192), (96, 80, 2, 70, 110), (256, 384, 1, 256, 384)])
+@pytest.mark.parametrize("h,w,nlev,hs,ws", [(128, 192, 3, 128, 192), (96, 80, 2, 70, 110), (256, 384, 1, 256, 384),
+                                            (128, 190, 2, 100, 150),      # real-photo geometry: 383x256-like odd level
+                                            (288, 300, 3, 288, 300)])
 def test_closure_vs_oracle(eng, vgg_weights, golden, h, w, nlev, hs, ws):
     c, s = _levels(h, w, nlev, 1), _levels(hs, ws, nlev, 2)
     _setup(eng, c, s)
