@@ -146,6 +146,8 @@ def main():
     ap.add_argument("--cpu-closures", type=int, default=2)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--time-all-kernels", action="store_true", help="event pairs around every launch (slower)")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (rehearsals)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
     ap.add_argument("--mode", default="jobs", choices=["jobs", "levels"],
                     help="N>1: 'jobs' = one independent job per GPU (weak scaling, no collective); 'levels' = ONE "
                          "job, pyramid levels sharded over the ranks, RCCL all-reduce of the pixel gradient per "
@@ -159,11 +161,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.dist_backend)
 
     from artstyletransfer_amd.engine import PixelOptimizer
     sharded = world > 1 and args.mode == "levels"

@@ -1,0 +1,24 @@
+"""GPU rehearsal (1 GPU, gloo, 2 ranks sharing cuda:0, or 1 rank): loss of every closure of the first optimiser steps."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from artstyletransfer_amd.engine import PixelOptimizer
+world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+torch.cuda.set_device(0)
+dist = None
+if world > 1:
+    import torch.distributed as dist
+    dist.init_process_group("gloo")
+eng, x, cfg, _ = bench.build_job(3, 0, 0)
+opt = PixelOptimizer(eng, "lbfgs", 10.0, 1)
+if world > 1:
+    opt.shard_levels(rank, world, dist)
+out = []
+for k in range(5):
+    info, rows = opt.step(x, cfg.content_weight, cfg.style_weight, cfg.tv_weight)
+    out += [float(r[-1]) for r in rows] + [int(info.accepted)]
+if rank == 0:
+    print("world", world, "totals/accept:", out, "x checksum", float(x.double().sum()))
+if dist is not None:
+    dist.barrier(); dist.destroy_process_group()
