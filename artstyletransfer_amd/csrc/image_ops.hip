@@ -91,21 +91,25 @@ __global__ void gauss_mask_acc_kernel(float* __restrict__ acc, const float* __re
     const double cy = (h - 1) * 0.5, cx = (w - 1) * 0.5;
     const double ry = (h / 2) - cy, rx = (w / 2) - cx;
     const double ref = exp(-(ry * ry) / (2.0 * sy * sy)) * exp(-(rx * rx) / (2.0 * sx * sx));
-    const size_t total = (size_t)h * w * C;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)((i / C) % w);
-        const int y = (int)(i / ((size_t)C * w));
+    const size_t pixels = (size_t)h * w;
+    // one envelope value per pixel, shared by its channels (the double exp dominates this kernel)
+    for (size_t p = (size_t)blockIdx.x * blockDim.x + threadIdx.x; p < pixels; p += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(p % w);
+        const int y = (int)(p / w);
         const double dy = y - cy, dx = x - cx;
         const double g = exp(-(dy * dy) / (2.0 * sy * sy)) * exp(-(dx * dx) / (2.0 * sx * sx)) / ref;
         const double mask = peripheral + g * (central - peripheral);
-        // numpy: float32 accumulator += float64 product, rounded to float32 on store
-        const double add = src ? (double)src[i] * mask : mask;
-        acc[i] = (float)((double)acc[i] + add);
+        for (int c = 0; c < C; ++c) {
+            const size_t i = p * C + c;
+            // numpy: float32 accumulator += float64 product, rounded to float32 on store
+            const double add = src ? (double)src[i] * mask : mask;
+            acc[i] = (float)((double)acc[i] + add);
+        }
     }
 }
 hipError_t launch_gauss_mask_acc(float* acc, const float* src, int h, int w, int C, double central, double peripheral,
                                  double disp, hipStream_t stream) {
-    hipLaunchKernelGGL(gauss_mask_acc_kernel, dim3(img_blocks((size_t)h * w * C)), dim3(256), 0, stream, acc, src, h, w, C,
+    hipLaunchKernelGGL(gauss_mask_acc_kernel, dim3(img_blocks((size_t)h * w)), dim3(256), 0, stream, acc, src, h, w, C,
                        central, peripheral, disp);
     return hipGetLastError();
 }

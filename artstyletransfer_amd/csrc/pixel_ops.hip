@@ -449,8 +449,17 @@ __global__ __launch_bounds__(256) void loss_assemble_kernel(LossAssembly la) {
         for (int k = 0; k < 5; ++k) {
             // C*C/32 partials: each thread adds its strided share in index order, then the fixed tree
             const int nb = (in.style_c[k] * in.style_c[k] + 31) / 32;
+            // (loads issued together, adds in index order: the latency of 32 dependent-looking loads was 100 us)
+            double v[32];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const int b = threadIdx.x + j * 256;
+                v[j] = b < nb ? in.style_partial[k][b] : 0.0;
+            }
             double t = 0.0;
-            for (int b = threadIdx.x; b < nb; b += 256) t += in.style_partial[k][b];
+#pragma unroll
+            for (int j = 0; j < 32; ++j) t += v[j];
+            for (int b = threadIdx.x + 32 * 256; b < nb; b += 256) t += in.style_partial[k][b];
             ss[k] = block_reduce_sum(t, sh);
         }
         if (threadIdx.x == 0) {

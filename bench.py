@@ -37,6 +37,24 @@ MFMA_PEAK = {"f32": 157.3, "bf16x3": 2500.0}
 MFMA_WORK_FACTOR = {"f32": 1.0, "bf16x3": 6.0}
 
 
+def pmc_traffic_per_launch(kernel_prefix):
+    """HBM GB per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json,
+    written by tools/summarize_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the same L=2
+    closure; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when the file is absent or
+    the workload is not the L=2 one it was collected on."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
+    try:
+        kernels = json.load(open(path))["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    n = b = 0
+    for name, e in kernels.items():
+        if name.startswith(kernel_prefix):
+            n += e["launches"]
+            b += e["fetch_bytes_corrected"] + e["write_bytes"]
+    return (b / n / 1e9) if n else None
+
+
 def mfma_roofline(mode, algorithmic_flops, ms, launches, extra=None):
     alg = algorithmic_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     hw = alg * MFMA_WORK_FACTOR[mode]
@@ -275,6 +293,11 @@ def main():
             oms, on, _ = eng.timing_totals(3)
             c1ms, c1n, c1fl = eng.timing_totals(2)
             out["roofline"] = mfma_roofline(eng.conv_mode(), fl, ms, n)
+            if args.levels == 3 and eng.conv_mode() == "bf16x3" and not sharded:
+                gb = pmc_traffic_per_launch("conv_bf3")
+                if gb is not None:
+                    out["roofline"]["traffic"] = gb
+                    out["roofline"]["traffic_unit"] = "GB of HBM per launch (rocprofv3 PMC passes, profiles/r01_pmc_hbm_traffic.json)"
             out["kernel_ms_per_closure"] = {"closure": cms / max(cn, 1), "conv3x3_mfma": ms / max(cn, 1)}
             if args.time_all_kernels:
                 out["kernel_ms_per_closure"].update({"gram_mfma": gms / max(cn, 1), "conv1_1": c1ms / max(cn, 1),

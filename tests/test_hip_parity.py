@@ -243,6 +243,38 @@ def test_closure_vs_oracle(eng, vgg_weights, golden, h, w, nlev, hs, ws):
         assert float((g0.double() ** 2).sum().cpu()) == pytest.approx(float(fx["grad.sq_sum"]), rel=1e-4)
 
 
+@pytest.mark.parametrize("h,w,nlev", [(128, 192, 2), (256, 384, 1)])
+def test_closure_accuracy_vs_fp64_truth(eng, vgg_weights, h, w, nlev):
+    """The oracle is itself an fp32 evaluation. Against the SAME closure evaluated in fp64 (the oracle's code on
+    double tensors) the HIP path must be as accurate as torch-fp32 is: losses to 1e-5, every feature map within
+    3x torch-fp32's own rounding error, and the gradient within 3x torch-fp32's own gradient error (which is
+    set by ReLU / max-pool decisions that flip under rounding, see GRAD_RTOL)."""
+    c, s = _levels(h, w, nlev, 1), _levels(h, w, nlev, 2)
+    _setup(eng, c, s)
+    w64 = [(a.double(), b.double()) for a, b in vgg_weights]
+    x_img = (0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(h, w, seed=9)).astype(np.float32)
+    xt = cpu_ref.prepare_img(x_img)
+    tg32 = [cpu_ref.LevelTargets(cpu_ref.prepare_img(ci), cpu_ref.prepare_img(si), vgg_weights) for ci, si in zip(c, s)]
+    tg64 = [cpu_ref.LevelTargets(cpu_ref.prepare_img(ci).double(), cpu_ref.prepare_img(si).double(), w64)
+            for ci, si in zip(c, s)]
+    loss64, grad64, rows64 = cpu_ref.closure_eval(xt.double(), tg64, w64, 1e3, 4e5, 1e2)
+    loss32, grad32, _ = cpu_ref.closure_eval(xt, tg32, vgg_weights, 1e3, 4e5, 1e2)
+    grad, losses = eng.closure(dev(xt), 1e3, 4e5, 1e2)
+    losses = losses.cpu().numpy()
+    assert float(losses[-1]) == pytest.approx(float(loss64), rel=1e-5)
+    check_rows(losses[:-1].reshape(nlev, 4), np.array(rows64), 2e-5)
+    err_hip = rel_l2(grad.cpu().numpy(), grad64.numpy())
+    err_t32 = rel_l2(grad32.numpy(), grad64.numpy())
+    print(f"gradient error vs fp64: hip {err_hip:.2e}, torch-fp32 {err_t32:.2e}")
+    assert err_hip < max(3.0 * err_t32, 2e-4)
+    f64 = cpu_ref.vgg19_features(xt.double(), w64)
+    f32 = cpu_ref.vgg19_features(xt, vgg_weights)
+    fh = eng.vgg_features(dev(xt))
+    for i, (a, b, t) in enumerate(zip(fh, f32, f64)):
+        e_hip, e_t32 = rel_l2(a.cpu().numpy(), t.numpy()), rel_l2(b.numpy(), t.numpy())
+        assert e_hip < max(3.0 * e_t32, 5e-7), (i, e_hip, e_t32)
+
+
 @pytest.mark.parametrize("env", [{"NST_CONV": "f32"}, {"NST_BATCH": "0"}, {"NST_BATCH": "0", "NST_SINGLE_STREAM": "1"},
                                  {"NST_CONV": "f32", "NST_BATCH": "0"}])
 def test_closure_execution_modes_agree(eng, vgg_weights, monkeypatch, env):
