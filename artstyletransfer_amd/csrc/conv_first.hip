@@ -27,7 +27,8 @@ __host__ __device__ constexpr int tap_off(int k) {
 __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restrict__ x, int H, int W,
                                                           const float* __restrict__ wk,
                                                           const float* __restrict__ bias, float* __restrict__ out,
-                                                          unsigned* __restrict__ bits_out) {
+                                                          unsigned* __restrict__ bits_out,
+                                                          unsigned* __restrict__ amax_out) {
     __shared__ float patch[3 * F_PLANE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -79,6 +80,7 @@ __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restric
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw[kk][1], acc[1][1], 0, 0, 0);
     }
 
+    float amax = 0.f;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int co = nt * 32 + l31;
@@ -92,19 +94,28 @@ __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restric
                 const int xx = x0 + (m & 15);
                 const bool inb = (y < H && xx < W);
                 const float v = fmaxf(acc[mt][nt][r] + bv, 0.f);
-                if (inb) out[((size_t)y * W + xx) * 64 + co] = v;
+                if (inb) {
+                    out[((size_t)y * W + xx) * 64 + co] = v;
+                    amax = fmaxf(amax, v);
+                }
                 if (bits_out) {
                     const unsigned long long bal = __ballot(v > 0.f);
                     if (l31 == 0 && inb) bits_out[((size_t)y * W + xx) * 2 + nt] = half ? (unsigned)(bal >> 32) : (unsigned)bal;
                 }
             }
     }
+    if (amax_out) {
+        // absmax of the output for the fp16-piece convolution that consumes it (conv_h2.hip)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        if (lane == 0) atomicMax(amax_out + ((blockIdx.x * 4 + wave) & (NST_AMAX_SLOTS - 1)), __float_as_uint(amax));
+    }
 }
 
 hipError_t launch_conv1_1_fwd(const float* x, int H, int W, const float* wk, const float* bias, float* out,
-                              unsigned* bits_out, hipStream_t stream) {
+                              unsigned* bits_out, unsigned* amax_out, hipStream_t stream) {
     const int blocks = ((H + F_TH - 1) / F_TH) * ((W + F_TW - 1) / F_TW);
-    hipLaunchKernelGGL(conv1_1_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, H, W, wk, bias, out, bits_out);
+    hipLaunchKernelGGL(conv1_1_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, H, W, wk, bias, out, bits_out, amax_out);
     return hipGetLastError();
 }
 

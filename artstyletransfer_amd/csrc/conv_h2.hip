@@ -1,0 +1,592 @@
+// conv_h2.hip - the 3x3 convolutions (forward and input gradient) on the gfx950 fp16 matrix pipe at
+// fp32-level accuracy with THREE MFMAs per product block (conv_bf3.hip needs six).
+//
+// Every fp32 operand tensor carries one power-of-two scale s (largest magnitude -> [2^14, 2^15), taken from
+// the absmax its producer recorded) and is cut into two fp16 pieces
+//       hi = fp16(a s)                      (round to nearest, 11 significant bits)
+//       lo = fp16((a s - hi) * 2^11)        (the residual a s - hi is exact in fp32; 11 more bits)
+// so that a s = hi + lo 2^-11 to 2^-23 relative - one bit short of fp32's own 2^-24 - for every element within
+// 2^-29 of the tensor maximum (smaller ones keep an absolute error below 2^-39 of the maximum).  The product is
+//       a b sA sB = hi_a hi_b + 2^-11 (hi_a lo_b + lo_a hi_b)            dropped: lo_a lo_b 2^-22
+// with the main term and the 2^-11-weighted cross terms accumulated in SEPARATE fp32 accumulators
+// (v_mfma_f32_32x32x16_f16; every fp16 x fp16 product is exact in fp32).  The cross accumulator's rounding
+// enters the result scaled by 2^-11, so the accumulation error is that of ONE fp32 chain; measured against an
+// fp64 evaluation the feature maps are as accurate as an fp32 MFMA's (tests/test_hip_parity.py,
+// tools/diag_accuracy.py).  3 x 32 = 96 matrix-pipe cycles per 32x32x16 block against 512 for
+// v_mfma_f32_32x32x2_f32: 5.3x the fp32-MFMA ceiling.
+//
+// Structure as conv_bf3.hip: implicit GEMM, halo patch of a 32-channel chunk staged once per 9 taps (cut while
+// being staged), per-tap weight slice double buffered, buffer loads with loop-invariant offsets, pinned
+// read/MFMA interleave.  LDS rows hold the two pieces of 32 channels (2 x 64 B) + 16 B pad = 144 B = 9 x 16 B:
+// 16 consecutive rows start on 16 distinct 16-B slots -> conflict-free ds_read_b128 fragments.
+// The epilogue records the absmax of what it stores (one atomicMax per wave into 64 slots; max is order
+// independent, so the result stays bitwise reproducible) for the launch that consumes that tensor.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <type_traits>
+
+#include "nst_kernels.h"
+
+namespace nst {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int KC = 32;            // channels per chunk
+constexpr int ROWB = 144;         // LDS row bytes: 2 pieces x 64 B + 16 B pad
+constexpr int WROWB = 128;        // global weight row bytes per (tap, cout, chunk): 2 pieces x 32 fp16
+constexpr float LO_UP = 2048.f;   // 2^11
+constexpr float LO_DOWN = 1.f / 2048.f;
+
+// NTW = 32-wide output-channel tiles per wave: 2 -> 64 x 64 wave tiles (128 accumulator registers, 8 fragment
+// reads per 12 MFMAs), 1 -> 64 x 32 (64 registers, 6 reads per 6 MFMAs; for the 64-channel layers and the small
+// tiles of under-filled launches, where the bigger tile does not fit the register file next to the staging).
+// LDS: the halo patch double buffered, the per-tap weight slice triple buffered (see the main K loop).
+template <int TH, int BN, int NTW>
+struct H2Cfg {
+    static constexpr int TW = 16;
+    static constexpr int PH = TH + 2, PW = TW + 2;
+    static constexpr int WM = TH / 4;            // waves along pixels (4 rows x 16 cols each)
+    static constexpr int WN = BN / (32 * NTW);
+    static constexpr int NT = 64 * WM * WN;
+    static constexpr int A_UNITS = PH * PW * (KC / 4);        // float4 units of the fp32 patch
+    static constexpr int A_PER_T = (A_UNITS + NT - 1) / NT;
+    static constexpr int B_UNITS = BN * (WROWB / 16);         // 16-byte units of the weight slice
+    static constexpr int B_PER_T = (B_UNITS + NT - 1) / NT;
+    // patch-row pitch rounded up to a multiple of 256 B (see conv_bf3.hip)
+    static constexpr int PROWB = ((PW * ROWB + 255) / 256) * 256;
+    static constexpr int A_BYTES = PH * PROWB;
+    static constexpr int B_BYTES = BN * ROWB;
+    static constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;
+    static_assert(NT == 512, "eight waves per workgroup");
+    static_assert(B_UNITS % NT == 0, "every lane stages the same number of weight units (no predication)");
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+};
+
+// Power-of-two scale that brings the recorded absmax (64 slots of non-negative float bit patterns) into
+// [2^14, 2^15), and its inverse.  An all-zero tensor gets a large finite scale (0 * s = 0).
+__device__ __forceinline__ void tensor_scale(const unsigned* __restrict__ slots, int lane, float& s, float& inv) {
+    unsigned m = slots[lane];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off);
+        m = o > m ? o : m;
+    }
+    int e = (int)((m >> 23) & 0xFFu);
+    e = e < 32 ? 32 : (e > 250 ? 250 : e);
+    s = __uint_as_float((unsigned)(268 - e) << 23);      // 2^(14 - (e - 127))
+    inv = __uint_as_float((unsigned)(e - 14) << 23);
+}
+
+// four scaled fp32 values -> their hi pieces and lo pieces (each 4 x fp16 = 8 bytes)
+__device__ __forceinline__ void cut2x4(const f32x4 v, const float s, u32x2& hi, u32x2& lo) {
+    const f32x2 x01 = {v[0] * s, v[1] * s}, x23 = {v[2] * s, v[3] * s};
+    const f16x2 h01 = __builtin_convertvector(x01, f16x2), h23 = __builtin_convertvector(x23, f16x2);
+    const f32x2 b01 = __builtin_convertvector(h01, f32x2), b23 = __builtin_convertvector(h23, f32x2);
+    const f32x2 r01 = (x01 - b01) * LO_UP, r23 = (x23 - b23) * LO_UP;
+    const f16x2 l01 = __builtin_convertvector(r01, f16x2), l23 = __builtin_convertvector(r23, f16x2);
+    hi = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+    lo = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+}
+
+}  // namespace
+
+// the whole workgroup program; (sp, ct) = spatial tile, output-channel tile of this workgroup
+template <int TH, int BN, int NTW>
+__device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, const int ct, const int slot_seed) {
+    using C = H2Cfg<TH, BN, NTW>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* ldsA = smem;                          // 2 patch buffers
+    unsigned char* ldsB = smem + 2 * C::A_BYTES;         // 3 weight-slice buffers
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave % C::WM;
+    const int wn = wave / C::WM;
+    const int half = lane >> 5;
+    const int l31 = lane & 31;
+
+    const int ty = sp / p.tiles_x;
+    const int tx = sp - ty * p.tiles_x;
+    const int y0 = ty * TH;
+    const int x0 = tx * C::TW;
+    const int n0 = ct * BN;
+
+    f32x4 ra[C::A_PER_T];
+    u32x4 rb[C::B_PER_T];
+
+    // Staging unit i of this lane: u = tid + i * NT; patch unit = (pixel u >> 3, channel quad u & 7), weight unit =
+    // (row u >> 3, 16-byte piece u & 7).  Addresses are recomputed where they are used, from a thread id the compiler
+    // cannot see through (`to`): kept in registers over the K loop they would push the fragment / accumulator set
+    // past the 256-register budget, and the compiler then sinks the global loads to the end of the stage.
+    auto a_lds_of = [&](int i, int to) -> int {
+        const int u = to + i * C::NT;
+        const int pix = u >> 3;
+        const int pr = pix / C::PW;
+        const int pc = pix - pr * C::PW;
+        return (u < C::A_UNITS) ? pr * C::PROWB + pc * ROWB + (u & 7) * 8 : -1;
+    };
+    // byte offset of patch unit i inside the image tensor; outside the image / unused: beyond the buffer (reads 0)
+    auto a_voff_of = [&](int i, int to, int cin) -> unsigned {
+        const int u = to + i * C::NT;
+        const int pix = u >> 3;
+        const int pr = pix / C::PW;
+        const int pc = pix - pr * C::PW;
+        const int gy = y0 - 1 + pr;
+        const int gx = x0 - 1 + pc;
+        // (unsigned compares fold the >= 0 tests; bitwise & keeps this a select instead of short-circuit branches)
+        const bool ok = (u < C::A_UNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+        return ok ? (unsigned)(((gy * p.W + gx) * cin + (u & 7) * 4) * 4) : 0xFFFFFF00u;
+    };
+    auto b_ok = [&](int, int) -> bool { return true; };       // B_UNITS is a multiple of the workgroup size
+    auto b_lds_of = [&](int i, int to) -> int { const int u = to + i * C::NT; return (u >> 3) * ROWB + (u & 7) * 16; };
+
+    // cut staged fp32 patch units [i0, i1) (held in r[0 .. i1-i0)) into two fp16 pieces, 8 bytes per piece
+    auto store_a = [&](unsigned char* dstA, const float s, const f32x4* r, const int i0, const int i1, const int to) {
+#pragma unroll
+        for (int i = i0; i < i1; ++i) {
+            const int off = a_lds_of(i, to);
+            if (off >= 0) {
+                u32x2 hi, lo;
+                cut2x4(r[i - i0], s, hi, lo);
+                unsigned char* row = dstA + off;
+                *reinterpret_cast<u32x2*>(row) = hi;
+                *reinterpret_cast<u32x2*>(row + 64) = lo;
+            }
+        }
+    };
+    // pre-cut weights: 16-byte units go to LDS as they are
+    auto store_b = [&](unsigned char* dst, const u32x4 (&r)[C::B_PER_T], const int to) {
+#pragma unroll
+        for (int i = 0; i < C::B_PER_T; ++i)
+            if (b_ok(i, to)) *reinterpret_cast<u32x4*>(dst + b_lds_of(i, to)) = r[i];
+    };
+    // fp32 weights (the Gram factor S of the second source): unit (row, q) = 4 floats, cut here
+    auto store_b_f32 = [&](unsigned char* dst, const float s, const int to) {
+#pragma unroll
+        for (int i = 0; i < C::B_PER_T; ++i)
+            if (b_ok(i, to)) {
+                u32x2 hi, lo;
+                cut2x4(__builtin_bit_cast(f32x4, rb[i]), s, hi, lo);
+                const int u = to + i * C::NT;
+                unsigned char* row = dst + (u >> 3) * ROWB + (u & 7) * 8;
+                *reinterpret_cast<u32x2*>(row) = hi;
+                *reinterpret_cast<u32x2*>(row + 64) = lo;
+            }
+    };
+    auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
+
+    f32x16 accm[2][NTW], accx[2][NTW];       // main products, cross products (weight 2^-11)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < NTW; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[a][b][r] = 0.f; accx[a][b][r] = 0.f; }
+
+    // fragment addresses: lane (r = lane & 31, h = lane >> 5) holds A[row r][k = 8h + j], B[k = 8h + j][col r]
+    const int prow = wm * 4 + (l31 >> 4);
+    const int pcol = l31 & 15;
+    const int a_off0 = (prow + 0) * C::PROWB + pcol * ROWB + half * 16;
+    const int a_off1 = (prow + 2) * C::PROWB + pcol * ROWB + half * 16;
+    const int b_off0 = (wn * 32 * NTW + l31) * ROWB + half * 16;
+
+    // the fragments of one k-step (16 channels): [m tile][piece], [n tile][piece]
+    struct Frags { f16x8 a[2][2]; f16x8 b[NTW][2]; };
+    auto request = [&](Frags& f, const unsigned char* abase, const unsigned char* bbase, const int ks) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f.a[0][s] = *reinterpret_cast<const f16x8*>(abase + a_off0 + s * 64 + ks * 32);
+            f.a[1][s] = *reinterpret_cast<const f16x8*>(abase + a_off1 + s * 64 + ks * 32);
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt)
+                f.b[nt][s] = *reinterpret_cast<const f16x8*>(bbase + b_off0 + nt * 32 * ROWB + s * 64 + ks * 32);
+        }
+    };
+    auto multiply = [&](const Frags& f) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[mt][1], f.b[nt][0], accx[mt][nt], 0, 0, 0);
+                accm[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[mt][0], f.b[nt][0], accm[mt][nt], 0, 0, 0);
+                accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.a[mt][0], f.b[nt][1], accx[mt][nt], 0, 0, 0);
+            }
+    };
+    constexpr int READS = 4 + 2 * NTW, MFMAS = 6 * NTW;       // per k-step
+    // one k-step: its MFMAs, with the fragment reads of the NEXT k-step issued one per MFMA in between
+    auto pin_kstep = [&]() {
+#pragma unroll
+        for (int g = 0; g < (READS < MFMAS ? READS : MFMAS); ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if (MFMAS > READS) __builtin_amdgcn_sched_group_barrier(0x008, MFMAS - READS, 0);
+    };
+    Frags f0, f1;
+
+    // ---- second K source: the Gram backward dF = F S (1 tap, fp32 weights cut here).  One stage per 32-channel
+    // chunk; patch and weights alternate between two LDS buffers and are staged one stage ahead (global loads two
+    // ahead), one barrier per stage.  Loads are buffer loads with loop-invariant per-lane offsets plus a scalar
+    // offset per chunk; out-of-image pixels get an offset beyond the buffer and read as zeros.
+    auto gram_source = [&](const float* src, const int cin, const float* wts, const float sa, const float sw) {
+        const int nch = cin / KC;
+        const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(src), 0, (unsigned)((size_t)p.H * p.W * cin * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(wts), 0, (unsigned)((size_t)p.Cout * cin * 4), 0x00020000);
+        unsigned a_voff[C::A_PER_T], b_voff[C::B_PER_T];
+#pragma unroll
+        for (int i = 0; i < C::A_PER_T; ++i) a_voff[i] = a_voff_of(i, tid, cin);
+#pragma unroll
+        for (int i = 0; i < C::B_PER_T; ++i) {
+            const int u = tid + i * C::NT;
+            b_voff[i] = b_ok(i, tid) ? (unsigned)(((u >> 3) * cin + (u & 7) * 4) * 4) : 0xFFFFFF00u;
+        }
+        auto load = [&](int chunk) {
+#pragma unroll
+            for (int i = 0; i < C::A_PER_T; ++i)
+                ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, a_voff[i], chunk * KC * 4, 0));
+#pragma unroll
+            for (int i = 0; i < C::B_PER_T; ++i)
+                rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, b_voff[i], (n0 * cin + chunk * KC) * 4, 0);
+        };
+        load(0);
+        store_a(ldsA, sa, ra, 0, C::A_PER_T, tid);
+        store_b_f32(ldsB, sw, tid);
+        if (nch > 1) load(1);
+        __syncthreads();
+        for (int c = 0; c < nch; ++c) {
+            const int cb = c & 1;
+            if (c + 1 < nch) {
+                // the other buffers were last read in stage c-1, which every wave has left
+                store_a(ldsA + (cb ^ 1) * C::A_BYTES, sa, ra, 0, C::A_PER_T, tid);
+                store_b_f32(ldsB + (cb ^ 1) * C::B_BYTES, sw, tid);
+                if (c + 2 < nch) load(c + 2);
+            }
+            const unsigned char* centre = ldsA + cb * C::A_BYTES + C::PROWB + ROWB;     // 1 tap: the centre of the patch
+            const unsigned char* bcur = ldsB + cb * C::B_BYTES;
+            request(f0, centre, bcur, 0);
+            request(f1, centre, bcur, 1);
+            multiply(f0);
+            multiply(f1);
+            __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+            pin_kstep();
+            __builtin_amdgcn_sched_group_barrier(0x008, MFMAS, 0);
+            __syncthreads();
+        }
+    };
+
+    // ---- main K source: the 3x3 convolution, one stage per (32-channel chunk c, tap t), two k-steps per stage.
+    // Software pipeline with ONE barrier per stage and no LDS latency behind it:
+    //   * weights: slice (g+2) is written to LDS at the top of stage g (triple buffer) from registers loaded during
+    //     stage g-1, so slice (g+1) is already visible while stage g computes;
+    //   * patch: chunk c+1 is loaded at tap 2 and cut into the other patch buffer at tap 6 of chunk c;
+    //   * fragments: those of k-step (g,1) are requested while (g,0) multiplies, those of (g+1,0) while (g,1)
+    //     multiplies - every wave leaves the barrier with its next operands in registers.
+    auto main_source = [&](const float* src, const int cin, const void* wts, const float sa) {
+        const int nch = cin / KC;
+        const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(src), 0, (unsigned)((size_t)p.H * p.W * cin * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<void*>(wts), 0, (unsigned)((size_t)9 * p.Cout * nch * WROWB), 0x00020000);
+        // patch units [i0, i1) of a chunk -> r[0 .. i1-i0)
+        auto load_a = [&](f32x4* r, int chunk, const int i0, const int i1, const int to) {
+#pragma unroll
+            for (int i = i0; i < i1; ++i)
+                r[i - i0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, a_voff_of(i, to, cin), chunk * KC * 4, 0));
+        };
+        // pre-cut weights: [tap][Cout][chunk][piece][32] fp16, i.e. 128 contiguous bytes per (tap, cout, chunk)
+        auto load_b = [&](u32x4 (&r)[C::B_PER_T], int chunk, int tap, const int to) {
+            const int soff = ((tap * p.Cout + n0) * nch + chunk) * WROWB;
+#pragma unroll
+            for (int i = 0; i < C::B_PER_T; ++i) {
+                const int u = to + i * C::NT;
+                const unsigned voff = b_ok(i, to) ? (unsigned)((u >> 3) * nch * WROWB + (u & 7) * 16) : 0xFFFFFF00u;
+                r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff, soff, 0);
+            }
+        };
+        auto tap_off = [](int t) { return (t / 3) * C::PROWB + (t % 3) * ROWB; };
+
+        // prologue: chunk 0 and the slices of stages 0, 1 into LDS, slice 2 into registers
+        {
+            u32x4 r0[C::B_PER_T], r1[C::B_PER_T];
+            load_a(ra, 0, 0, C::A_PER_T, tid);
+            load_b(r0, 0, 0, tid);
+            load_b(r1, 0, 1, tid);
+            load_b(rb, 0, 2, tid);
+            __syncthreads();          // the previous source is done with the LDS buffers
+            store_a(ldsA, sa, ra, 0, C::A_PER_T, tid);
+            store_b(ldsB, r0, tid);
+            store_b(ldsB + C::B_BYTES, r1, tid);
+        }
+        __syncthreads();
+        request(f0, ldsA + tap_off(0), ldsB, 0);
+
+        for (int c = 0; c < nch; ++c) {
+            unsigned char* acur = ldsA + (c & 1) * C::A_BYTES;
+            unsigned char* anext = ldsA + ((c + 1) & 1) * C::A_BYTES;
+            // The stage body is branch-free so that the compiler's s_waitcnt counts stay exact (a vmcnt merged over
+            // control flow waits for ALL loads, i.e. for the patch loads from HBM issued one stage earlier).  In the
+            // last chunk the look-ahead re-loads valid addresses (chunk cn) into buffers nobody reads any more.
+            const int cn = (c + 1 < nch) ? c + 1 : c;
+            const int to = opaque(tid);
+            constexpr int AH = (C::A_PER_T + 1) / 2;      // the next patch is staged in two halves (registers)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                // top of stage g = 9 c + t: slice g+2 to LDS, slice g+3 on its way
+                store_b(ldsB + ((t + 2) % 3) * C::B_BYTES, rb, to);
+                if (t + 3 < 9) load_b(rb, c, t + 3, to);
+                else load_b(rb, cn, t + 3 - 9, to);
+                if (t == 0) load_a(ra, cn, 0, AH, to);
+                if (t == 4) load_a(ra, cn, AH, C::A_PER_T, to);
+                // keep the loads HERE: left free, the scheduler sinks them towards the end of the stage (their
+                // registers are then shared with the fragments) and the next stage stalls on them
+                __builtin_amdgcn_sched_barrier(0);
+                if (t == 3) store_a(anext, sa, ra, 0, AH, to);
+                if (t == 7) store_a(anext, sa, ra, AH, C::A_PER_T, to);
+                const unsigned char* bcur = ldsB + (t % 3) * C::B_BYTES;
+                // k-step 0
+                request(f1, acur + tap_off(t), bcur, 1);
+                multiply(f0);
+                pin_kstep();
+                // k-step 1, fetching the first fragments of the next stage
+                if (t + 1 < 9) request(f0, acur + tap_off(t + 1), ldsB + ((t + 1) % 3) * C::B_BYTES, 0);
+                else request(f0, anext + tap_off(0), ldsB, 0);
+                multiply(f1);
+                pin_kstep();
+                __syncthreads();
+            }
+        }
+    };
+
+    // scales of the operand tensors (recorded absmax -> power of two) and of the frozen weights
+    float sa1, ia1;
+    tensor_scale(p.amax_in, lane, sa1, ia1);
+    const float inv = ia1 * p.wt_h2_inv;
+    if (p.in2) {
+        // The Gram backward rides on this launch with its own scales; it runs first and the accumulators are then
+        // re-expressed in the scale of the main source (powers of two: exact).
+        float sa2, ia2, sw2, iw2;
+        tensor_scale(p.amax_in2, lane, sa2, ia2);
+        tensor_scale(p.amax_w2, lane, sw2, iw2);
+        gram_source(p.in2, p.Cin2, p.wt2_f32, sa2, sw2);
+        const float ratio = (ia2 * sa1) * (iw2 * (1.f / p.wt_h2_inv));
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < NTW; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { accm[a][b][r] *= ratio; accx[a][b][r] *= ratio; }
+    }
+    main_source(p.in, p.Cin, p.wt_h2, sa1);
+
+    // epilogue: D[m][n]: n = lane&31, m = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int words = p.Cout >> 5;          // ReLU bit-mask words per pixel
+    float amax = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        const int co = n0 + wn * 32 * NTW + nt * 32 + l31;
+        const int cw = (n0 + wn * 32 * NTW + nt * 32) >> 5;
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int y = y0 + wm * 4 + mt * 2 + (m >> 4);
+                const int x = x0 + (m & 15);
+                const bool inb = (y < p.H && x < p.W);
+                const size_t pix = (size_t)y * p.W + x;
+                const size_t idx = pix * p.Cout + co;
+                float v = fmaf(accx[mt][nt][r], LO_DOWN, accm[mt][nt][r]) * inv + bv;
+                if (p.addend && inb) v += p.addend[idx];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.bits_in) {
+                    // the 32 lanes of a half-wave read the same word: one bit per output channel
+                    const unsigned wv = inb ? p.bits_in[pix * words + cw] : 0u;
+                    v = ((wv >> l31) & 1u) ? v : 0.f;
+                } else if (p.mask) {
+                    v = (inb && p.mask[idx] > 0.f) ? v : 0.f;
+                }
+                if (p.bits_out) {
+                    // ReLU mask of this output for the backward pass: bit = lane, one word per half-wave
+                    const unsigned long long bal = __ballot(v > 0.f);
+                    if (l31 == 0 && inb) p.bits_out[pix * words + cw] = half ? (unsigned)(bal >> 32) : (unsigned)bal;
+                }
+                accm[mt][nt][r] = v;
+                if (inb) {
+                    p.out[idx] = v;
+                    amax = fmaxf(amax, fabsf(v));
+                }
+            }
+            if (p.pool_out) {
+                // 2x2/2 max pool of the tile rows (2 mt, 2 mt + 1): the four window elements sit in this
+                // lane's registers r, r+1, r+8, r+9
+                const int py = (y0 + wm * 4 + mt * 2) >> 1;
+                const int PH2 = p.H >> 1, PW2 = p.W >> 1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int r = 2 * j;
+                    const float mx = fmaxf(fmaxf(accm[mt][nt][r], accm[mt][nt][r + 1]),
+                                           fmaxf(accm[mt][nt][r + 8], accm[mt][nt][r + 9]));
+                    const int mcol = (r & 3) + 8 * (r >> 2) + 4 * half;      // column of register r (row 0 of the pair)
+                    const int px = (x0 + mcol) >> 1;
+                    if (py < PH2 && px < PW2) p.pool_out[((size_t)py * PW2 + px) * p.Cout + co] = mx;
+                }
+            }
+        }
+    }
+    if (p.amax_out) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        if (lane == 0) atomicMax(p.amax_out + ((slot_seed * (C::NT / 64) + wave) & (NST_AMAX_SLOTS - 1)), __float_as_uint(amax));
+    }
+}
+
+template <int TH, int BN, int NTW>
+__global__ __launch_bounds__(512, 2) void conv_h2_kernel(ConvParams p) {
+    const int n_ct = p.Cout / BN;
+    conv_h2_body<TH, BN, NTW>(p, blockIdx.x / n_ct, blockIdx.x % n_ct, blockIdx.x);
+}
+
+// One launch = one layer over several images (the pyramid levels of a closure), see conv_bf3.hip.
+template <int TH, int BN, int NTW>
+__global__ __launch_bounds__(512, 2) void conv_h2_batch_kernel(ConvBatch b) {
+    const int n_ct = b.Cout / BN;
+    const int sp_all = blockIdx.x / n_ct;
+    int i = 0;
+    while (i + 1 < b.n && sp_all >= b.img[i].tile_end) ++i;
+    const ConvImage& im = b.img[i];
+    ConvParams p;
+    p.in = im.in; p.wt = nullptr; p.wt_bf = nullptr; p.bias = b.bias; p.addend = im.addend; p.mask = im.mask; p.out = im.out;
+    p.H = im.H; p.W = im.W; p.Cin = b.Cin; p.Cout = b.Cout; p.relu = b.relu;
+    p.tiles_x = im.tiles_x; p.tiles_y = 0; p.partial = nullptr; p.partial_floats = 0; p.ksplit = 1;
+    p.in2 = im.in2; p.Cin2 = b.Cin2; p.wt2_bf = nullptr; p.bits_out = im.bits_out; p.bits_in = im.bits_in;
+    p.pool_out = im.pool_out;
+    p.wt_h2 = b.wt_h2; p.wt_h2_inv = b.wt_h2_inv; p.wt2_f32 = im.wt2_f32;
+    p.amax_in = im.amax_in; p.amax_in2 = im.amax_in2; p.amax_w2 = im.amax_w2; p.amax_out = im.amax_out;
+    conv_h2_body<TH, BN, NTW>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), blockIdx.x % n_ct, blockIdx.x);
+}
+
+template <int TH, int BN, int NTW>
+static hipError_t init_one() {
+    constexpr int lds = H2Cfg<TH, BN, NTW>::LDS_BYTES;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_kernel<TH, BN, NTW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_batch_kernel<TH, BN, NTW>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
+hipError_t conv_h2_init_device() {
+    hipError_t e = init_one<16, 128, 2>();
+    if (e == hipSuccess) e = init_one<8, 128, 1>();
+    if (e == hipSuccess) e = init_one<16, 64, 1>();
+    return e;
+}
+
+// a 128-channel launch whose 16-row tiles cannot fill 256 CUs twice over uses 8-row tiles
+static int h2_tile_rows(int Cout, long blocks16) {
+    if (Cout % 128 != 0) return 16;
+    return blocks16 < 400 ? 8 : 16;
+}
+
+template <int TH, int BN, int NTW>
+static void launch_batch_cfg(const ConvBatch& b, int blocks, hipStream_t stream) {
+    constexpr int lds = H2Cfg<TH, BN, NTW>::LDS_BYTES;
+    constexpr int nt = H2Cfg<TH, BN, NTW>::NT;
+    hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW>), dim3(blocks), dim3(nt), lds, stream, b);
+}
+template <int TH, int BN, int NTW>
+static void launch_single_cfg(const ConvParams& p, int blocks, hipStream_t stream) {
+    constexpr int lds = H2Cfg<TH, BN, NTW>::LDS_BYTES;
+    constexpr int nt = H2Cfg<TH, BN, NTW>::NT;
+    hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW>), dim3(blocks), dim3(nt), lds, stream, p);
+}
+
+static bool h2_operands_ok(const void* wt, const unsigned* amax_in, int Cin, int Cout, const float* in2, const float* wt2,
+                           const unsigned* a2, const unsigned* w2, int Cin2) {
+    if (Cin % 32 != 0 || Cout % 64 != 0 || !wt || !amax_in) return false;
+    if (in2 && (!wt2 || !a2 || !w2 || Cin2 % 32 != 0 || Cin2 != Cout)) return false;
+    return true;
+}
+
+// fills tiles_x / tile_end of every image and launches one grid over all of them
+hipError_t launch_conv_h2_batch(const ConvBatch& b0, hipStream_t stream) {
+    if (b0.n < 1 || b0.n > 8) return hipErrorInvalidValue;
+    ConvBatch b = b0;
+    const bool wide = (b.Cout % 128 == 0);
+    long blocks16 = 0;
+    for (int i = 0; i < b.n; ++i) {
+        const ConvImage& im = b.img[i];
+        if (!h2_operands_ok(b.wt_h2, im.amax_in, b.Cin, b.Cout, im.in2, im.wt2_f32, im.amax_in2, im.amax_w2, b.Cin2))
+            return hipErrorInvalidValue;
+        if ((size_t)im.H * im.W * b.Cin * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
+        blocks16 += (long)((im.H + 15) / 16) * ((im.W + 15) / 16) * (b.Cout / 128);
+    }
+    const int th = h2_tile_rows(b.Cout, blocks16), bn = wide ? 128 : 64;
+    int tiles = 0;
+    for (int i = 0; i < b.n; ++i) {
+        b.img[i].tiles_x = (b.img[i].W + 15) / 16;
+        tiles += b.img[i].tiles_x * ((b.img[i].H + th - 1) / th);
+        b.img[i].tile_end = tiles;
+    }
+    const int blocks = tiles * (b.Cout / bn);
+    if (!wide) launch_batch_cfg<16, 64, 1>(b, blocks, stream);
+    else if (th == 8) launch_batch_cfg<8, 128, 1>(b, blocks, stream);
+    else launch_batch_cfg<16, 128, 2>(b, blocks, stream);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_h2(const ConvParams& p0, hipStream_t stream) {
+    if (!h2_operands_ok(p0.wt_h2, p0.amax_in, p0.Cin, p0.Cout, p0.in2, p0.wt2_f32, p0.amax_in2, p0.amax_w2, p0.Cin2))
+        return hipErrorInvalidValue;
+    // 32-bit buffer offsets: the input tensor must stay below 4 GiB (callers fall back to conv_mfma.hip beyond)
+    if ((size_t)p0.H * p0.W * p0.Cin * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
+    ConvParams p = p0;
+    p.ksplit = 1;
+    const bool wide = (p.Cout % 128 == 0);
+    const long blocks16 = (long)((p.H + 15) / 16) * ((p.W + 15) / 16) * (p.Cout / 128);
+    const int th = h2_tile_rows(p.Cout, blocks16), bn = wide ? 128 : 64;
+    p.tiles_x = (p.W + 15) / 16;
+    p.tiles_y = (p.H + th - 1) / th;
+    const int blocks = p.tiles_x * p.tiles_y * (p.Cout / bn);
+    if (!wide) launch_single_cfg<16, 64, 1>(p, blocks, stream);
+    else if (th == 8) launch_single_cfg<8, 128, 1>(p, blocks, stream);
+    else launch_single_cfg<16, 128, 2>(p, blocks, stream);
+    return hipGetLastError();
+}
+
+// ---- absmax of a tensor into its 64 slots (producers without an epilogue of their own) -----------------------
+__global__ __launch_bounds__(256) void absmax_slots_kernel(const float* __restrict__ x, size_t n, unsigned* __restrict__ slots) {
+    float m = 0.f;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[n4 * 4 + threadIdx.x]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0)
+        atomicMax(slots + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (NST_AMAX_SLOTS - 1)), __float_as_uint(m));
+}
+hipError_t launch_absmax_slots(const float* x, size_t n, unsigned* slots, hipStream_t stream) {
+    size_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(absmax_slots_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, x, n, slots);
+    return hipGetLastError();
+}
+
+}  // namespace nst

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
                                                           float divisor, const float* __restrict__ target, float coef,
                                                           float* __restrict__ gram_out, float* __restrict__ S,
                                                           unsigned short* __restrict__ S_bf,
+                                                          unsigned* __restrict__ S_amax,
                                                           double* __restrict__ mse_partial) {
     __shared__ float sh[8][32];
     __shared__ double shd[32];
@@ -243,6 +244,7 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
 #pragma unroll
         for (int g = 1; g < 8; ++g) t += sh[g][el];
         double sq = 0.0;
+        float sabs = 0.f;
         if (e < CC) {
             const float g = t / divisor;      // torch: gram /= ch*h*w
             if (gram_out) gram_out[e] = g;
@@ -250,6 +252,7 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
                 const float d = g - target[e];
                 sq = (double)d * (double)d;
                 const float sv = coef * d;
+                sabs = fabsf(sv);
                 if (S) S[e] = sv;
                 if (S_bf) {
                     // the same value cut into three bf16 pieces in conv_bf3's weight layout
@@ -267,6 +270,12 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
             }
         }
         shd[el] = sq;
+        if (S_amax) {
+            // absmax of S for the fp16-piece convolution that multiplies by it (conv_h2.hip); lanes 0..31 here
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) sabs = fmaxf(sabs, __shfl_xor(sabs, off));
+            if (el == 0) atomicMax(S_amax + (blockIdx.x & (NST_AMAX_SLOTS - 1)), __float_as_uint(sabs));
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0 && mse_partial) {
@@ -279,9 +288,10 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
 int gram_finish_blocks(int C) { return (int)(((size_t)C * C + 31) / 32); }
 
 hipError_t launch_gram_finish(const float* part, int nslabs, int C, float divisor, const float* target, float coef,
-                              float* gram_out, float* S, unsigned short* S_bf, double* mse_partial, hipStream_t stream) {
+                              float* gram_out, float* S, unsigned short* S_bf, unsigned* S_amax, double* mse_partial,
+                              hipStream_t stream) {
     hipLaunchKernelGGL(gram_finish_kernel, dim3(gram_finish_blocks(C)), dim3(256), 0, stream, part, nslabs, C,
-                       gram_ts(C), divisor, target, coef, gram_out, S, (C % 32 == 0) ? S_bf : nullptr, mse_partial);
+                       gram_ts(C), divisor, target, coef, gram_out, S, (C % 32 == 0) ? S_bf : nullptr, S_amax, mse_partial);
     return hipGetLastError();
 }
 

@@ -42,8 +42,16 @@ struct ActSet {                 // activations of one forward pass, NHWC
     unsigned* bits[NL] = {};     // ReLU bit-masks ([h*w][C/32] words) of the layers whose mask the backward reads
     bool bits_valid[NL] = {};    // written by the last forward pass (false when that layer ran split-K / fp32)
     bool pooled[4] = {};         // pool[k] already produced by the conv epilogue of the last forward pass
+    // absmax records for the fp16-piece convolutions (conv_h2.hip): AMAX_IDS x NST_AMAX_SLOTS words.
+    // ids: act[l] -> l; the Gram factor S of style layer q -> NL + q; the gradient w.r.t. the pre-ReLU output of
+    // layer l (or a bound of it: the pooled gradient it was un-pooled from) -> NL + 5 + l
+    unsigned* amax = nullptr;
     size_t bytes = 0;
 };
+constexpr int AMAX_IDS = 2 * NST_VGG19_CONVS + 5;
+inline unsigned* amax_act(const ActSet& a, int l) { return a.amax + (size_t)l * NST_AMAX_SLOTS; }
+inline unsigned* amax_S(const ActSet& a, int q) { return a.amax + (size_t)(NST_VGG19_CONVS + q) * NST_AMAX_SLOTS; }
+inline unsigned* amax_grad(const ActSet& a, int l) { return a.amax + (size_t)(NST_VGG19_CONVS + 5 + l) * NST_AMAX_SLOTS; }
 
 enum KClass { K_CONV3 = 0, K_GRAM = 1, K_CONV1 = 2, K_OTHER = 3, K_NCLASS = 4 };
 
@@ -81,7 +89,13 @@ struct nst_ctx {
     float* wd[NL] = {};
     void* wf_bf[NL] = {};       // the same weights cut into 3 bf16 pieces (conv_bf3.hip layout)
     void* wd_bf[NL] = {};
-    int conv_bf3 = 1;           // 1: 3x3 convs on the bf16 pipe with 3-piece operands; 0: fp32 MFMA
+    void* wf_h2[NL] = {};       // ... cut into 2 scaled fp16 pieces (conv_h2.hip layout), true = pieces * w*_h2_inv
+    void* wd_h2[NL] = {};
+    float wf_h2_inv[NL] = {};
+    float wd_h2_inv[NL] = {};
+    // 3x3 convs: 2 = fp16 pipe, 2 scaled pieces per operand (3 MFMAs per product block; default),
+    //            1 = bf16 pipe, 3 exact pieces (6 MFMAs), 0 = fp32 MFMA
+    int conv_mode = 2;
     int batched = 1;            // 1: one conv launch per layer covering every pyramid level (one stream)
     // hipGraph of the closure: captured the second time the same (buffers, weights, mask) are seen
     int use_graph = 0;          // measured: no gain (the host already runs ~16 ms ahead of the GPU); NST_GRAPH=1 enables
@@ -177,6 +191,9 @@ int alloc_acts(nst_ctx* ctx, ActSet& a, int h, int w) {
         NSTCHK(dev_alloc_t(ctx, &a.bits[m], nw));
         a.bytes += nw * 4;
     }
+    NSTCHK(dev_alloc_t(ctx, &a.amax, (size_t)AMAX_IDS * NST_AMAX_SLOTS));
+    a.bytes += (size_t)AMAX_IDS * NST_AMAX_SLOTS * 4;
+    if (hipMemset(a.amax, 0, (size_t)AMAX_IDS * NST_AMAX_SLOTS * 4) != hipSuccess) return fail(ctx, NST_E_HIP, "hipMemset failed");
     a.splitk_floats = need;
     if (need) {
         NSTCHK(dev_alloc_t(ctx, &a.splitk, need));
@@ -188,6 +205,7 @@ void free_acts(nst_ctx* ctx, ActSet& a) {
     for (int l = 0; l < NL; ++l) { dev_free(a.act[l]); a.act[l] = nullptr; }
     for (int k = 0; k < 4; ++k) { dev_free(a.pool[k]); a.pool[k] = nullptr; }
     dev_free(a.splitk); a.splitk = nullptr; a.splitk_floats = 0;
+    dev_free(a.amax); a.amax = nullptr;
     for (int l = 0; l < NL; ++l) { dev_free(a.bits[l]); a.bits[l] = nullptr; a.bits_valid[l] = false; }
     if (ctx->bytes >= a.bytes) ctx->bytes -= a.bytes;
     a.bytes = 0;
@@ -220,6 +238,31 @@ void make_bf3(const float* w, int taps, int rows, int K, std::vector<uint16_t>& 
             }
 }
 
+// w: [taps][rows][K] fp32  ->  out: [taps][rows][K/32][2][32] fp16 pieces of w * s, s = the power of two that
+// brings the largest |w| into [2^14, 2^15); *inv = 1 / s (same cut as conv_h2.hip::cut2x4)
+void make_h2(const float* w, int taps, int rows, int K, std::vector<uint16_t>& out, float* inv) {
+    const size_t n = (size_t)taps * rows * K;
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));
+    int ex = 0;
+    if (mx > 0.f) (void)std::frexp(mx, &ex);          // mx = f * 2^ex, f in [0.5, 1)
+    const float s = std::ldexp(1.f, 15 - ex);          // mx * s in [2^14, 2^15)
+    *inv = std::ldexp(1.f, ex - 15);
+    const int nch = K / 32;
+    out.assign((size_t)taps * rows * nch * 64, 0);
+    for (int t = 0; t < taps; ++t)
+        for (int r = 0; r < rows; ++r)
+            for (int k = 0; k < K; ++k) {
+                const float x = w[((size_t)t * rows + r) * K + k] * s;
+                const _Float16 hi = (_Float16)x;
+                const _Float16 lo = (_Float16)((x - (float)hi) * 2048.f);
+                uint16_t uh, ul;
+                std::memcpy(&uh, &hi, 2); std::memcpy(&ul, &lo, 2);
+                const size_t base = (((size_t)t * rows + r) * nch + k / 32) * 64 + (k % 32);
+                out[base] = uh; out[base + 32] = ul;
+            }
+}
+
 int pool_index_after(int l) {
     for (int k = 0; k < 4; ++k) if (kPoolAfter[k] == l) return k;
     return -1;
@@ -245,17 +288,23 @@ struct Timer {
 
 double conv_flops(int h, int w, int cin, int cout, int taps) { return 2.0 * h * w * (double)cin * cout * taps; }
 
-// 3x3 conv dispatch: bf16 3-piece kernel unless disabled or the tensor needs 64-bit addressing
+// the 16-bit-piece kernels address with 32-bit buffer offsets: tensors from 4 GiB up go to the fp32 kernel
+bool uses_pieces(const nst_ctx* ctx, const ConvParams& p) {
+    return ctx->conv_mode != 0 && (size_t)p.H * p.W * p.Cin * 4 < 0xFFFFFF00ull;
+}
+// 3x3 conv dispatch by mode; whatever kernel runs, the absmax record of the output is produced when asked for
 hipError_t launch_conv3(nst_ctx* ctx, const ConvParams& p, hipStream_t s) {
-    if (ctx->conv_bf3 && (size_t)p.H * p.W * p.Cin * 4 < 0xFFFFFF00ull) return launch_conv_bf3(p, s);
-    return launch_conv_mfma(p, 9, s);
+    if (uses_pieces(ctx, p)) return ctx->conv_mode == 2 ? launch_conv_h2(p, s) : launch_conv_bf3(p, s);
+    hipError_t e = launch_conv_mfma(p, 9, s);
+    if (e == hipSuccess && ctx->conv_mode == 2 && p.amax_out)
+        e = launch_absmax_slots(p.out, (size_t)p.H * p.W * p.Cout, p.amax_out, s);
+    return e;
 }
-
-bool uses_bf3(const nst_ctx* ctx, const ConvParams& p) {
-    return ctx->conv_bf3 && (size_t)p.H * p.W * p.Cin * 4 < 0xFFFFFF00ull;
-}
+// true when the launch runs as ONE piece kernel, whose epilogue can write ReLU bit-masks / the pooled map and
+// take a second K source (the fp16 kernel never splits K; the bf16 one may)
 bool bf3_unsplit(const nst_ctx* ctx, const ConvParams& p) {
-    if (!uses_bf3(ctx, p)) return false;
+    if (!uses_pieces(ctx, p)) return false;
+    if (ctx->conv_mode == 2) return true;
     const int S = conv_bf3_ksplit(p.H, p.W, p.Cin, p.Cout);
     return !(p.partial && S > 1 && (size_t)S * p.H * p.W * p.Cout <= p.partial_floats);
 }
@@ -264,10 +313,12 @@ bool bf3_unsplit(const nst_ctx* ctx, const ConvParams& p) {
 int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s, int last_layer = NL - 1) {
     for (int l = 0; l < NL; ++l) a.bits_valid[l] = false;
     for (int k = 0; k < 4; ++k) a.pooled[k] = false;
+    const bool h2 = ctx->conv_mode == 2;
+    if (h2) HIPCHK(ctx, hipMemsetAsync(a.amax, 0, (size_t)(NL + 5) * NST_AMAX_SLOTS * 4, s));     // act + S records
     {
         Timer t(ctx, s, K_CONV1, conv_flops(h, w, 3, 64, 9));
-        unsigned* bits = ctx->conv_bf3 ? a.bits[0] : nullptr;
-        HIPCHK(ctx, launch_conv1_1_fwd(x, h, w, ctx->w11k, ctx->bias[0], a.act[0], bits, s));
+        unsigned* bits = ctx->conv_mode ? a.bits[0] : nullptr;
+        HIPCHK(ctx, launch_conv1_1_fwd(x, h, w, ctx->w11k, ctx->bias[0], a.act[0], bits, h2 ? amax_act(a, 0) : nullptr, s));
         a.bits_valid[0] = bits != nullptr;
     }
     for (int l = 1; l <= last_layer; ++l) {
@@ -277,6 +328,11 @@ int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s
         p.in = in; p.wt = ctx->wf[l]; p.bias = ctx->bias[l]; p.addend = nullptr; p.mask = nullptr; p.out = a.act[l];
         p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCin[l]; p.Cout = kCout[l]; p.relu = 1;
         p.partial = a.splitk; p.partial_floats = a.splitk_floats; p.wt_bf = ctx->wf_bf[l];
+        if (h2) {
+            p.wt_h2 = ctx->wf_h2[l]; p.wt_h2_inv = ctx->wf_h2_inv[l];
+            p.amax_in = amax_act(a, l - 1);       // the pooled map's maximum is its source's
+            p.amax_out = amax_act(a, l);
+        }
         const int pa = pool_index_after(l);
         const bool fuse = bf3_unsplit(ctx, p);        // the epilogue extras exist in the unsplit bf3 kernel only
         if (fuse) {
@@ -304,6 +360,7 @@ int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s
 struct Inject {
     const float* S = nullptr;        // Gram backward: dF = F * S (1x1 conv of the activation itself)
     const void* S_bf = nullptr;      // the same S cut into bf16 pieces (conv_bf3 weight layout), if available
+    const unsigned* S_amax = nullptr; // absmax record of S (conv_h2), if available
     const float* direct = nullptr;   // or a ready NHWC gradient
     bool content = false;            // or the content MSE gradient (closure only)
 };
@@ -316,6 +373,8 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
              int h, int w, hipStream_t s) {
     float* cur = gbuf0;     // holds the gradient w.r.t. the pre-ReLU output of the layer being processed
     float* oth = gbuf1;
+    const bool h2 = ctx->conv_mode == 2;
+    if (h2) HIPCHK(ctx, hipMemsetAsync(amax_grad(a, 0), 0, (size_t)NL * NST_AMAX_SLOTS * 4, s));
     // top: layer 12
     {
         const int l = NL - 1;
@@ -332,6 +391,7 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
         } else {
             HIPCHK(ctx, hipMemsetAsync(cur, 0, n * 4, s));
         }
+        if (h2) HIPCHK(ctx, launch_absmax_slots(cur, n, amax_grad(a, l), s));
     }
     for (int l = NL - 1; l >= 1; --l) {
         // cur = g(pre-ReLU of layer l), dims of layer l, kCout[l] channels.  dgrad -> gradient w.r.t.
@@ -341,6 +401,11 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
         p.in = cur; p.wt = ctx->wd[l]; p.out = oth;
         p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCout[l]; p.Cout = kCin[l];
         p.partial = a.splitk; p.partial_floats = a.splitk_floats; p.wt_bf = ctx->wd_bf[l];
+        if (h2) {
+            p.wt_h2 = ctx->wd_h2[l]; p.wt_h2_inv = ctx->wd_h2_inv[l];
+            p.amax_in = amax_grad(a, l);
+            p.amax_out = amax_grad(a, l - 1);     // when un-pooled next, this bounds the un-pooled gradient too
+        }
         if (pk >= 0) {
             {
                 Timer t(ctx, s, K_CONV3, conv_flops(p.H, p.W, p.Cin, p.Cout, 9), p.H, p.W, p.Cin, p.Cout, 9, -l);
@@ -355,9 +420,10 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
             const Inject& in = inj[m];
             const bool fuse = bf3_unsplit(ctx, p);
             double extra_flops = 0;
-            if (in.S && in.S_bf && fuse) {
+            if (in.S && fuse && (h2 ? in.S_amax != nullptr : in.S_bf != nullptr)) {
                 // Gram backward rides on this launch as a second K source: acc += act[m] * S
                 p.in2 = a.act[m]; p.Cin2 = kCout[m]; p.wt2_bf = in.S_bf;
+                p.wt2_f32 = in.S; p.amax_in2 = amax_act(a, m); p.amax_w2 = in.S_amax;
                 extra_flops = conv_flops(a.h[m], a.w[m], kCout[m], kCout[m], 1);
             } else if (in.S) {
                 ConvParams q{};
@@ -390,14 +456,16 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
 }
 
 int gram_of(nst_ctx* ctx, const float* f_nhwc, size_t N, int C, float divisor, float* part, const float* target,
-            float coef, float* gram_out, float* S, unsigned short* S_bf, double* mse_partial, hipStream_t s) {
+            float coef, float* gram_out, float* S, unsigned short* S_bf, unsigned* S_amax, double* mse_partial,
+            hipStream_t s) {
     const int ns = gram_nsplit(C, N);
     {
         Timer t(ctx, s, K_GRAM, 2.0 * (double)N * C * C);
         HIPCHK(ctx, launch_gram_partial(f_nhwc, N, C, ns, part, s));
     }
     Timer t(ctx, s, K_OTHER, 0);
-    HIPCHK(ctx, launch_gram_finish(part, gram_nslabs(C, ns), C, divisor, target, coef, gram_out, S, S_bf, mse_partial, s));
+    HIPCHK(ctx, launch_gram_finish(part, gram_nslabs(C, ns), C, divisor, target, coef, gram_out, S, S_bf, S_amax,
+                                   mse_partial, s));
     return NST_OK;
 }
 
@@ -425,24 +493,28 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
         else HIPCHK(ctx, hipMemsetAsync(gi[i], 0, (size_t)3 * ctx->lv[i].h * ctx->lv[i].w * sizeof(float), s));
     }
     if (n == 0) return NST_OK;
+    const bool h2 = ctx->conv_mode == 2;
     // ---- forward
     for (int k = 0; k < n; ++k) {
         LevelWs& L = ctx->lv[lv[k]];
         ActSet& a = L.acts;
         for (int l = 0; l < NL; ++l) a.bits_valid[l] = false;
         for (int q = 0; q < 4; ++q) a.pooled[q] = false;
+        if (h2) HIPCHK(ctx, hipMemsetAsync(a.amax, 0, (size_t)AMAX_IDS * NST_AMAX_SLOTS * 4, s));
         {
             Timer t(ctx, s, K_OTHER, 0);
             HIPCHK(ctx, launch_tv_partial(xi[lv[k]], 3, L.h, L.w, L.tv_partial, s));
         }
         Timer t(ctx, s, K_CONV1, conv_flops(L.h, L.w, 3, 64, 9));
-        HIPCHK(ctx, launch_conv1_1_fwd(xi[lv[k]], L.h, L.w, ctx->w11k, ctx->bias[0], a.act[0], a.bits[0], s));
+        HIPCHK(ctx, launch_conv1_1_fwd(xi[lv[k]], L.h, L.w, ctx->w11k, ctx->bias[0], a.act[0], a.bits[0],
+                                       h2 ? amax_act(a, 0) : nullptr, s));
         a.bits_valid[0] = true;
     }
     for (int l = 1; l < NL; ++l) {
         const int pk = pool_index_after(l - 1), pa = pool_index_after(l);
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wf_bf[l]; b.bias = ctx->bias[l]; b.Cin = kCin[l]; b.Cout = kCout[l]; b.relu = 1;
+        b.wt_h2 = ctx->wf_h2[l]; b.wt_h2_inv = ctx->wf_h2_inv[l];
         double flops = 0;
         for (int k = 0; k < n; ++k) {
             ActSet& a = ctx->lv[lv[k]].acts;
@@ -453,10 +525,11 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
             im.pool_out = (pa >= 0) ? a.pool[pa] : nullptr;
             a.bits_valid[l] = a.bits[l] != nullptr;
             if (pa >= 0) a.pooled[pa] = true;
+            im.amax_in = amax_act(a, l - 1); im.amax_out = amax_act(a, l);
             flops += conv_flops(im.H, im.W, b.Cin, b.Cout, 9);
         }
         Timer t(ctx, s, K_CONV3, flops, b.img[0].H, b.img[0].W, b.Cin, b.Cout, 9, l);
-        HIPCHK(ctx, launch_conv_bf3_batch(b, s));
+        HIPCHK(ctx, h2 ? launch_conv_h2_batch(b, s) : launch_conv_bf3_batch(b, s));
     }
     // ---- style losses: Gram matrices, S = d loss / d G folded for the backward
     for (int k = 0; k < n; ++k) {
@@ -468,7 +541,7 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
             const double chw = (double)C * (double)N;
             const float coef = (float)((double)sw * 4.0 / (5.0 * (double)C * C * chw));
             NSTCHK(gram_of(ctx, L.acts.act[l], N, C, (float)chw, L.gram_part, L.gram_t[q], coef, nullptr, L.S[q],
-                           L.S_bf[q], L.style_partial[q], s));
+                           L.S_bf[q], h2 ? amax_S(L.acts, q) : nullptr, L.style_partial[q], s));
         }
     }
     // ---- backward
@@ -481,8 +554,14 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
         ConvParams p{};
         p.in = a.act[l]; p.wt = L.S[4]; p.out = cur[k]; p.mask = a.act[l];
         p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCout[l]; p.Cout = kCout[l];
-        Timer t(ctx, s, K_GRAM, conv_flops(p.H, p.W, p.Cin, p.Cout, 1));
-        HIPCHK(ctx, launch_conv_mfma(p, 1, s));
+        {
+            Timer t(ctx, s, K_GRAM, conv_flops(p.H, p.W, p.Cin, p.Cout, 1));
+            HIPCHK(ctx, launch_conv_mfma(p, 1, s));
+        }
+        if (h2) {
+            Timer t(ctx, s, K_OTHER, 0);
+            HIPCHK(ctx, launch_absmax_slots(cur[k], (size_t)p.H * p.W * p.Cout, amax_grad(a, l), s));
+        }
     }
     for (int l = NL - 1; l >= 1; --l) {
         const int pk = pool_index_after(l - 1);
@@ -491,6 +570,7 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
         for (int q = 0; q < 5; ++q) if (kStyleLayer[q] == m) style_q = q;
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wd_bf[l]; b.bias = nullptr; b.Cin = kCout[l]; b.Cout = kCin[l]; b.relu = 0;
+        b.wt_h2 = ctx->wd_h2[l]; b.wt_h2_inv = ctx->wd_h2_inv[l];
         b.Cin2 = (pk < 0 && style_q >= 0) ? kCout[m] : 0;
         double flops = 0;
         for (int k = 0; k < n; ++k) {
@@ -498,10 +578,12 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
             ActSet& a = L.acts;
             ConvImage& im = b.img[k];
             im.in = cur[k]; im.out = oth[k]; im.H = a.h[l]; im.W = a.w[l];
+            im.amax_in = amax_grad(a, l); im.amax_out = amax_grad(a, l - 1);
             flops += conv_flops(im.H, im.W, b.Cin, b.Cout, 9);
             if (pk >= 0) continue;
             if (style_q >= 0) {
                 im.in2 = a.act[m]; im.wt2_bf = L.S_bf[style_q];
+                im.wt2_f32 = L.S[style_q]; im.amax_in2 = amax_act(a, m); im.amax_w2 = amax_S(a, style_q);
                 flops += conv_flops(a.h[m], a.w[m], kCout[m], kCout[m], 1);
             } else if (m == kContentLayer) {
                 Timer t(ctx, s, K_OTHER, 0);
@@ -513,7 +595,7 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
         }
         {
             Timer t(ctx, s, K_CONV3, flops, b.img[0].H, b.img[0].W, b.Cin, b.Cout, 9, -l);
-            HIPCHK(ctx, launch_conv_bf3_batch(b, s));
+            HIPCHK(ctx, h2 ? launch_conv_h2_batch(b, s) : launch_conv_bf3_batch(b, s));
         }
         for (int k = 0; k < n; ++k) {
             ActSet& a = ctx->lv[lv[k]].acts;
@@ -607,9 +689,13 @@ int nst_ctx_create(int device, const float* const* weights, const float* const* 
     if (hipSetDevice(device) != hipSuccess) { ctx->err = "hipSetDevice failed"; return bail(NST_E_HIP); }
     hipError_t e = conv_mfma_init_device();
     if (e == hipSuccess) e = conv_bf3_init_device();
+    if (e == hipSuccess) e = conv_h2_init_device();
     if (e == hipSuccess) e = gram_init_device();
     const char* cm = getenv("NST_CONV");
-    if (cm && std::strcmp(cm, "f32") == 0) ctx->conv_bf3 = 0;
+    if (cm && std::strcmp(cm, "f32") == 0) ctx->conv_mode = 0;
+    else if (cm && std::strcmp(cm, "bf16x3") == 0) ctx->conv_mode = 1;
+    else if (cm && std::strcmp(cm, "f16x2") == 0) ctx->conv_mode = 2;
+    else if (cm && cm[0]) { ctx->err = "NST_CONV must be f32, bf16x3 or f16x2"; return bail(NST_E_ARG); }
     const char* bm = getenv("NST_BATCH");
     if (bm && bm[0] == '0') ctx->batched = 0;
     const char* gm = getenv("NST_GRAPH");
@@ -654,6 +740,9 @@ int nst_ctx_create(int device, const float* const* weights, const float* const* 
         make_bf3(tmp.data(), 9, co, ci, tmp16);
         if (dev_alloc(ctx, &ctx->wf_bf[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
         if (hipMemcpy(ctx->wf_bf[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+        make_h2(tmp.data(), 9, co, ci, tmp16, &ctx->wf_h2_inv[l]);
+        if (dev_alloc(ctx, &ctx->wf_h2[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
+        if (hipMemcpy(ctx->wf_h2[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
         // input gradient: a conv with "Cout" = ci and "Cin" = co: wd[tap'][ci][co] = W[co][ci][2-ky'][2-kx']
         for (int t = 0; t < 9; ++t) {
             const int ky = 2 - t / 3, kx = 2 - t % 3;
@@ -665,6 +754,9 @@ int nst_ctx_create(int device, const float* const* weights, const float* const* 
         make_bf3(tmp.data(), 9, ci, co, tmp16);
         if (dev_alloc(ctx, &ctx->wd_bf[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
         if (hipMemcpy(ctx->wd_bf[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+        make_h2(tmp.data(), 9, ci, co, tmp16, &ctx->wd_h2_inv[l]);
+        if (dev_alloc(ctx, &ctx->wd_h2[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
+        if (hipMemcpy(ctx->wd_h2[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
     }
     if (hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
@@ -680,7 +772,7 @@ void nst_ctx_destroy(nst_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (int i = 0; i < NST_MAX_LEVELS; ++i) free_level(ctx, ctx->lv[i]);
-    for (int l = 0; l < NL; ++l) { dev_free(ctx->wf[l]); dev_free(ctx->wd[l]); dev_free(ctx->bias[l]); dev_free(ctx->wf_bf[l]); dev_free(ctx->wd_bf[l]); }
+    for (int l = 0; l < NL; ++l) { dev_free(ctx->wf[l]); dev_free(ctx->wd[l]); dev_free(ctx->bias[l]); dev_free(ctx->wf_bf[l]); dev_free(ctx->wd_bf[l]); dev_free(ctx->wf_h2[l]); dev_free(ctx->wd_h2[l]); }
     dev_free(ctx->w11k); dev_free(ctx->w11d);
     if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
     if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
@@ -691,7 +783,7 @@ void nst_ctx_destroy(nst_ctx* ctx) {
     delete ctx;
 }
 
-int nst_conv_mode(const nst_ctx* ctx) { return ctx ? ctx->conv_bf3 : -1; }
+int nst_conv_mode(const nst_ctx* ctx) { return ctx ? ctx->conv_mode : -1; }
 
 int nst_ctx_bytes(const nst_ctx* ctx, size_t* bytes) {
     if (!ctx || !bytes) return fail(nullptr, NST_E_ARG, "null argument");
@@ -765,7 +857,7 @@ int nst_level_set_targets(nst_ctx* ctx, int level, const float* content, const f
         const int C = kCout[l];
         const size_t N = (size_t)sa.h[l] * sa.w[l];
         r = gram_of(ctx, sa.act[l], N, C, (float)((double)C * sa.h[l] * sa.w[l]), part, nullptr, 0.f, L.gram_t[k],
-                    nullptr, nullptr, nullptr, s);
+                    nullptr, nullptr, nullptr, nullptr, s);
     }
     hipError_t e = hipStreamSynchronize(s);
     free_acts(ctx, sa);
@@ -792,7 +884,7 @@ int nst_closure(nst_ctx* ctx, const float* x, float cw, float sw, float tvw, flo
 
 static bool batch_eligible(const nst_ctx* ctx) {
     // needs the bf16 conv kernels (32-bit buffer offsets) and enough tiles to be worth it
-    return ctx->batched && ctx->conv_bf3 && (size_t)ctx->lv[0].h * ctx->lv[0].w * 64 * 4 < 0xFFFFFF00ull &&
+    return ctx->batched && ctx->conv_mode && (size_t)ctx->lv[0].h * ctx->lv[0].w * 64 * 4 < 0xFFFFFF00ull &&
            (ctx->levels > 1 || (size_t)ctx->lv[0].h * ctx->lv[0].w >= (size_t)256 * 256);
 }
 
@@ -887,9 +979,10 @@ static int closure_record(nst_ctx* ctx, const float* x, float cw, float sw, floa
             // style = mean_k mse(G_k, Gt_k); dL/dG = sw/5 * 2 (G-Gt)/C^2; dF = 2 * dL/dG * F / (C h w)
             const float coef = (float)((double)sw * 4.0 / (5.0 * (double)C * C * chw));
             NSTCHK(gram_of(ctx, L.acts.act[l], N, C, (float)chw, L.gram_part, L.gram_t[k], coef, nullptr, L.S[k],
-                           L.S_bf[k], L.style_partial[k], s));
+                           L.S_bf[k], ctx->conv_mode == 2 ? amax_S(L.acts, k) : nullptr, L.style_partial[k], s));
             inj[l].S = L.S[k];
             inj[l].S_bf = L.S_bf[k];
+            inj[l].S_amax = ctx->conv_mode == 2 ? amax_S(L.acts, k) : nullptr;
         }
         inj[kContentLayer].content = true;
         ContentJob cj{L.content_t, L.content_n, (float)((double)cw * 2.0 / (double)L.content_n), L.content_partial};
@@ -1042,7 +1135,7 @@ int nst_gram(nst_ctx* ctx, const float* f, int C, int h, int w, int normalize, f
     if (r == NST_OK) r = dev_alloc_t(ctx, &part, (size_t)gram_nsplit(C, N) * C * C);
     if (r == NST_OK && launch_chw_to_hwc(f, C, h, w, nhwc, s) != hipSuccess) r = fail(ctx, NST_E_HIP, "chw_to_hwc launch failed");
     if (r == NST_OK)
-        r = gram_of(ctx, nhwc, N, C, normalize ? (float)((double)C * h * w) : 1.f, part, nullptr, 0.f, gram, nullptr, nullptr, nullptr, s);
+        r = gram_of(ctx, nhwc, N, C, normalize ? (float)((double)C * h * w) : 1.f, part, nullptr, 0.f, gram, nullptr, nullptr, nullptr, nullptr, s);
     hipError_t e = hipStreamSynchronize(s);
     dev_free(nhwc); dev_free(part);
     if (r != NST_OK) return r;

@@ -29,7 +29,17 @@ struct ConvParams {
     unsigned* bits_out;   // optional: ReLU bit-mask of the output, [H*W][Cout/32] words (bit = channel & 31)
     const unsigned* bits_in;  // optional: replaces `mask` (same layout, of the tensor the gradient flows into)
     float* pool_out;      // optional: 2x2/2 max-pooled output [H/2][W/2][Cout]
+    // conv_h2 only (bits_out / bits_in / pool_out / in2 / Cin2 above apply too) -------------------------
+    const void* wt_h2;    // [9][Cout][Cin/32][2 pieces][32] fp16, the weights times 1/wt_h2_inv (see conv_h2.hip)
+    float wt_h2_inv;      // power of two: true weight = (hi + lo 2^-11) * wt_h2_inv
+    const float* wt2_f32; // weights of the second K source, fp32 [Cout][Cin2] (cut in the kernel)
+    const unsigned* amax_in;   // NST_AMAX_SLOTS words: absmax of `in` (float bit patterns, max over the slots)
+    const unsigned* amax_in2;  // ... of `in2`
+    const unsigned* amax_w2;   // ... of `wt2_f32`
+    unsigned* amax_out;        // optional: absmax of `out` is recorded here (atomic max; zero it beforehand)
 };
+
+constexpr int NST_AMAX_SLOTS = 64;
 
 // One image (pyramid level) of a batched conv_bf3 launch; the layer's weights / channel counts are shared.
 struct ConvImage {
@@ -44,6 +54,12 @@ struct ConvImage {
     float* pool_out;
     int H, W;
     int tiles_x, tile_end;   // filled by the launcher
+    // conv_h2 only
+    const float* wt2_f32;
+    const unsigned* amax_in;
+    const unsigned* amax_in2;
+    const unsigned* amax_w2;
+    unsigned* amax_out;
 };
 struct ConvBatch {
     ConvImage img[8];
@@ -51,6 +67,8 @@ struct ConvBatch {
     const void* wt_bf;
     const float* bias;
     int Cin, Cout, Cin2, relu;
+    const void* wt_h2;       // conv_h2 only
+    float wt_h2_inv;
 };
 
 // conv_mfma.hip
@@ -67,11 +85,19 @@ hipError_t launch_conv_bf3(const ConvParams& p, hipStream_t stream);
 hipError_t launch_conv_bf3_batch(const ConvBatch& b, hipStream_t stream);
 int conv_bf3_ksplit(int H, int W, int Cin, int Cout);
 
+// conv_h2.hip: the same on the fp16 matrix pipe with 2-piece scaled operands (3 MFMAs per product block)
+hipError_t conv_h2_init_device();
+hipError_t launch_conv_h2(const ConvParams& p, hipStream_t stream);
+hipError_t launch_conv_h2_batch(const ConvBatch& b, hipStream_t stream);
+// absmax of n floats into NST_AMAX_SLOTS slots (atomic max; zero them beforehand)
+hipError_t launch_absmax_slots(const float* x, size_t n, unsigned* slots, hipStream_t stream);
+
 // conv_first.hip: conv1_1 (3 -> 64) forward from the planar image, and its input gradient
 // wk: [28][64] (k = c*9 + ky*3 + kx, row 27 zero); bias [64]; out NHWC 64, ReLU applied.
-// bits_out (nullable): ReLU bit-mask of the output, [H*W][2] words
+// bits_out (nullable): ReLU bit-mask of the output, [H*W][2] words; amax_out (nullable): NST_AMAX_SLOTS words
+// receiving the absmax of the output (atomic max)
 hipError_t launch_conv1_1_fwd(const float* x, int H, int W, const float* wk, const float* bias, float* out,
-                              unsigned* bits_out, hipStream_t stream);
+                              unsigned* bits_out, unsigned* amax_out, hipStream_t stream);
 // g: [H][W][64] gradient w.r.t. the pre-ReLU conv1_1 output; wd: [9][64][4] flipped taps
 // (wd[t][co][c] = W[co][c][2-ky][2-kx], c = 3 unused 0); gx planar (3,H,W), overwritten.
 hipError_t launch_conv1_1_dgrad(const float* g, int H, int W, const float* wd, float* gx, hipStream_t stream);
@@ -141,8 +167,10 @@ hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, floa
 // mse_partial: gram_finish_blocks(C) doubles.  `nslabs` = gram_nslabs(C, nsplit).
 int gram_nslabs(int C, int nsplit);
 int gram_finish_blocks(int C);
+// S_amax (nullable): NST_AMAX_SLOTS words receiving the absmax of S (atomic max; zero them beforehand).
 hipError_t launch_gram_finish(const float* part, int nslabs, int C, float divisor, const float* target, float coef,
-                              float* gram_out, float* S, unsigned short* S_bf, double* mse_partial, hipStream_t stream);
+                              float* gram_out, float* S, unsigned short* S_bf, unsigned* S_amax, double* mse_partial,
+                              hipStream_t stream);
 
 // image_ops.hip: job set-up on the device (pyramid resize, structured-noise initial image) ---------------------
 hipError_t launch_resize_hwc(const float* src, int h, int w, int C, float* dst, int oh, int ow, hipStream_t stream);

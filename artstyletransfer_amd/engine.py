@@ -116,8 +116,10 @@ class StyleEngine:
         return grad, losses
 
     def conv_mode(self) -> str:
-        """'bf16x3' (3-piece bf16 operands on the bf16 matrix pipe, fp32 accumulate) or 'f32' (fp32 MFMA)."""
-        return "bf16x3" if self.lib.nst_conv_mode(self.ctx) == 1 else "f32"
+        """How the 3x3 convolutions are evaluated (env NST_CONV at context creation): 'f16x2' (default: two scaled
+        fp16 pieces per fp32 operand, 3 MFMAs per product block, fp32 accumulate), 'bf16x3' (three exact bf16
+        pieces, 6 MFMAs) or 'f32' (fp32 MFMA)."""
+        return {0: "f32", 1: "bf16x3", 2: "f16x2"}[self.lib.nst_conv_mode(self.ctx)]
 
     def bytes(self) -> int:
         n = C.c_size_t()

@@ -33,8 +33,15 @@ import torch
 # MI355X_MICROARCH.md dense matrix peaks: fp32 MFMA 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32), bf16 MFMA ~2500 TFLOP/s.
 # In the default conv mode every fp32 product is evaluated as 6 bf16 MFMA products (3-piece exact operand split),
 # so the matrix pipe executes 6x the algorithmic FLOPs and is priced against the bf16 peak.
-MFMA_PEAK = {"f32": 157.3, "bf16x3": 2500.0}
-MFMA_WORK_FACTOR = {"f32": 1.0, "bf16x3": 6.0}
+MFMA_PEAK = {"f32": 157.3, "bf16x3": 2500.0, "f16x2": 2500.0}
+MFMA_WORK_FACTOR = {"f32": 1.0, "bf16x3": 6.0, "f16x2": 3.0}
+MFMA_KERNEL = {"f32": "conv_mfma_kernel", "bf16x3": "conv_bf3_kernel", "f16x2": "conv_h2_kernel"}
+MFMA_DTYPE = {"f32": "f32",
+              "bf16x3": "bf16 (3 exact pieces per fp32 operand, 6 MFMAs per product, fp32 accumulate)",
+              "f16x2": "f16 (2 scaled pieces per fp32 operand = 22 significand bits, 3 MFMAs per product, main and "
+                       "2^-11-weighted cross terms in separate fp32 accumulators)"}
+DTYPE = {"f32": "f32", "bf16x3": "f32 via bf16x3 split (6 bf16 MFMAs per product, f32 accumulate)",
+         "f16x2": "f32 via f16x2 split (3 f16 MFMAs per product, f32 accumulate)"}
 
 
 def pmc_traffic_per_launch(kernel_prefix):
@@ -58,9 +65,9 @@ def pmc_traffic_per_launch(kernel_prefix):
 def mfma_roofline(mode, algorithmic_flops, ms, launches, extra=None):
     alg = algorithmic_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     hw = alg * MFMA_WORK_FACTOR[mode]
-    out = {"bound": "mfma", "kernel": "conv_bf3_kernel" if mode == "bf16x3" else "conv_mfma_kernel",
+    out = {"bound": "mfma", "kernel": MFMA_KERNEL[mode],
            "what": "3x3 conv forward + input gradient (+ fused Gram backward)",
-           "mfma_dtype": "bf16 (3 exact pieces per fp32 operand, 6 MFMAs per product, fp32 accumulate)" if mode == "bf16x3" else "f32",
+           "mfma_dtype": MFMA_DTYPE[mode],
            "achieved": hw, "peak": MFMA_PEAK[mode], "unit": "TFLOP/s", "frac": hw / MFMA_PEAK[mode],
            "algorithmic_tflops": alg, "traffic": None, "launches": launches, "avg_launch_ms": ms / max(launches, 1),
            "flops_per_launch_avg": algorithmic_flops / max(launches, 1)}
@@ -270,7 +277,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if sharded else "weak",
             "vs_baseline": None,
-            "dtype": "f32 via bf16x3 split (6 bf16 MFMAs per product, f32 accumulate)" if eng.conv_mode() == "bf16x3" else "f32",
+            "dtype": DTYPE[eng.conv_mode()],
             "data": "synthetic",
             "config": {"workload": f"pyramid style transfer, levels_num={args.levels} "
                                    f"({'+'.join(f'{W >> l}x{H >> l}' for l in range(args.levels))}), "
@@ -293,8 +300,8 @@ def main():
             oms, on, _ = eng.timing_totals(3)
             c1ms, c1n, c1fl = eng.timing_totals(2)
             out["roofline"] = mfma_roofline(eng.conv_mode(), fl, ms, n)
-            if args.levels == 3 and eng.conv_mode() == "bf16x3" and not sharded:
-                gb = pmc_traffic_per_launch("conv_bf3")
+            if args.levels == 3 and eng.conv_mode() == "f16x2" and not sharded:
+                gb = pmc_traffic_per_launch("conv_h2")
                 if gb is not None:
                     out["roofline"]["traffic"] = gb
                     out["roofline"]["traffic_unit"] = "GB of HBM per launch (rocprofv3 PMC passes, profiles/r01_pmc_hbm_traffic.json)"
