@@ -149,6 +149,203 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restri
     }
 }
 
+// ---- the same partial Gram on the fp16 matrix pipe (see conv_h2.hip for the arithmetic) ------------------------------
+// Both operands are the SAME tensor with one power-of-two scale s (from its recorded absmax), cut into two fp16
+// pieces, hi = fp16(x s), lo = fp16((x s - hi) 2^11); G s^2 = sum hi hi' + 2^-11 sum (hi lo' + lo hi') with the main
+// and the cross products in separate fp32 accumulators: 3 v_mfma_f32_32x32x16_f16 per 32x32x16 block.  That MFMA
+// wants 8 consecutive k (= pixels) per lane, so the NHWC map is transposed while it is staged: a lane loads 8
+// pixels of ONE channel (a wave's 64 lanes = 64 consecutive channels of a pixel: 256-byte segments) and writes
+// their 8 hi and 8 lo pieces as two 16-byte words into the channel's LDS row
+// [row = channel][piece][32 pixels] (128 B + 16 B pad: conflict-free ds_read_b128 fragments).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+template <int TS>
+struct GramH2Cfg {
+    static constexpr int KP = (TS == 128) ? 32 : 128;          // pixels per staged chunk
+    static constexpr int SIDES = (TS == 128) ? 2 : 1;
+    static constexpr int ROWB = 144;
+    static constexpr int ROWS = (TS == 128) ? 256 : 256;       // 2 sides x 128 channels | 4 pixel slices x 64 channels
+    static constexpr int BUF_BYTES = ROWS * ROWB;
+    static constexpr int UNITS = TS * (KP / 8);                // (channel, 8-pixel group) units per side per chunk
+    static constexpr int PER_T = UNITS / 256;
+    static constexpr int LDS_BYTES = 2 * BUF_BYTES;            // 72 KiB: two workgroups per CU
+};
+
+template <int TS>
+__global__ __launch_bounds__(256, 2) void gram_h2_kernel(const float* __restrict__ f, size_t N, int C, int nsplit,
+                                                         size_t pix_per_split, const unsigned* __restrict__ amax,
+                                                         float* __restrict__ part) {
+    using G = GramH2Cfg<TS>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    const int split = blockIdx.x % nsplit;
+    int tp = blockIdx.x / nsplit;
+    const int T = C / TS;
+    int ti = 0;
+    while (tp >= T - ti) { tp -= T - ti; ++ti; }
+    const int tj = ti + tp;
+    const bool diag = (ti == tj);
+
+    const size_t p0 = (size_t)split * pix_per_split;
+    size_t p1 = p0 + pix_per_split;
+    if (p1 > N) p1 = N;
+    const int nchunks = (p0 < p1) ? (int)((p1 - p0 + G::KP - 1) / G::KP) : 0;
+
+    // scale from the recorded absmax (same rule as conv_h2.hip::tensor_scale)
+    float sc, inv;
+    {
+        unsigned m = amax[lane];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)m, off);
+            m = o > m ? o : m;
+        }
+        int e = (int)((m >> 23) & 0xFFu);
+        e = e < 32 ? 32 : (e > 250 ? 250 : e);
+        sc = __uint_as_float((unsigned)(268 - e) << 23);
+        inv = __uint_as_float((unsigned)(e - 14) << 23);
+    }
+
+    // pixels beyond p1 read as zeros (buffer range check)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f), 0,
+                                                                          (unsigned)(p1 * (size_t)C * 4), 0x00020000);
+    float st[G::SIDES][G::PER_T][8];
+    auto load = [&](int chunk) {
+        const unsigned base = (unsigned)((p0 + (size_t)chunk * G::KP) * (size_t)C * 4);
+#pragma unroll
+        for (int sd = 0; sd < G::SIDES; ++sd) {
+            if (sd == 1 && diag) break;
+            const int cb = (sd == 0 ? ti : tj) * TS;
+#pragma unroll
+            for (int i = 0; i < G::PER_T; ++i) {
+                const int u = tid + i * 256;
+                const int ch = u % TS, gg = u / TS;
+                const unsigned voff = (unsigned)(((gg * 8) * C + cb + ch) * 4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    st[sd][i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, base + (unsigned)(j * C * 4), 0));
+            }
+        }
+    };
+    auto store = [&](int buf) {
+        unsigned char* base = smem_h2 + buf * G::BUF_BYTES;
+#pragma unroll
+        for (int sd = 0; sd < G::SIDES; ++sd) {
+            if (sd == 1 && diag) break;
+#pragma unroll
+            for (int i = 0; i < G::PER_T; ++i) {
+                const int u = tid + i * 256;
+                const int ch = u % TS, gg = u / TS;
+                const int row = (TS == 128) ? sd * 128 + ch : (gg >> 2) * 64 + ch;
+                unsigned hi[4], lo[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x2 x = {st[sd][i][2 * k] * sc, st[sd][i][2 * k + 1] * sc};
+                    const f16x2 h = __builtin_convertvector(x, f16x2);
+                    const f32x2 r = (x - __builtin_convertvector(h, f32x2)) * 2048.f;
+                    const f16x2 l = __builtin_convertvector(r, f16x2);
+                    hi[k] = __builtin_bit_cast(unsigned, h);
+                    lo[k] = __builtin_bit_cast(unsigned, l);
+                }
+                unsigned char* dst = base + row * G::ROWB + (gg & 3) * 16;
+                *reinterpret_cast<u32x4*>(dst) = u32x4{hi[0], hi[1], hi[2], hi[3]};
+                *reinterpret_cast<u32x4*>(dst + 64) = u32x4{lo[0], lo[1], lo[2], lo[3]};
+            }
+        }
+    };
+
+    const int wm = (TS == 128) ? (wave & 1) : 0;
+    const int wn = (TS == 128) ? (wave >> 1) : 0;
+    const int arow = (TS == 128) ? wm * 64 : wave * 64;
+    const int brow = (TS == 128) ? (diag ? 0 : 128) + wn * 64 : wave * 64;
+    const int a_off = (arow + l31) * G::ROWB + half * 16;
+    const int b_off = (brow + l31) * G::ROWB + half * 16;
+
+    f32x16 accm[2][2], accx[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[a][b][r] = 0.f; accx[a][b][r] = 0.f; }
+
+    if (nchunks > 0) {
+        load(0);
+        store(0);
+        if (nchunks > 1) load(1);
+    }
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int cb = c & 1;
+        if (c + 1 < nchunks) {
+            store(cb ^ 1);              // the other buffer was last read in chunk c-1, which every wave has left
+            if (c + 2 < nchunks) load(c + 2);
+        }
+        const unsigned char* base = smem_h2 + cb * G::BUF_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 fa[2][2], fb[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) {
+                    fa[t][pc] = *reinterpret_cast<const f16x8*>(base + a_off + t * 32 * G::ROWB + pc * 64 + ks * 32);
+                    fb[t][pc] = *reinterpret_cast<const f16x8*>(base + b_off + t * 32 * G::ROWB + pc * 64 + ks * 32);
+                }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][1], fb[nt][0], accx[mt][nt], 0, 0, 0);
+                    accm[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], fb[nt][0], accm[mt][nt], 0, 0, 0);
+                    accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[mt][0], fb[nt][1], accx[mt][nt], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    const float inv2 = inv * inv;
+    float* slab = part + (size_t)split * C * C;
+    if (TS == 128) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int row = ti * TS + wm * 64 + mt * 32 + m;
+                    const int col = tj * TS + wn * 64 + nt * 32 + l31;
+                    slab[(size_t)row * C + col] = fmaf(accx[mt][nt][r], 1.f / 2048.f, accm[mt][nt][r]) * inv2;
+                }
+    } else {
+        // the four waves hold partial sums over disjoint pixel slices: combine through LDS in wave order
+        float* red = reinterpret_cast<float*>(smem_h2);
+        float* mine = red + wave * 4096;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    mine[(mt * 32 + m) * 64 + nt * 32 + l31] = fmaf(accx[mt][nt][r], 1.f / 2048.f, accm[mt][nt][r]);
+                }
+        __syncthreads();
+        for (int e = tid; e < 4096; e += 256) {
+            const float sum = ((red[e] + red[4096 + e]) + red[8192 + e]) + red[12288 + e];
+            const int row = ti * TS + (e >> 6), col = tj * TS + (e & 63);
+            slab[(size_t)row * C + col] = sum * inv2;
+        }
+    }
+}
+
 // generic fallback for channel counts that are not a multiple of 64 (unit-parity API only)
 __global__ void gram_generic_kernel(const float* __restrict__ f, size_t N, int C, float* __restrict__ part) {
     const int i = blockIdx.x / C, j = blockIdx.x % C;
@@ -189,12 +386,21 @@ hipError_t gram_init_device() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_partial_kernel<128>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, GramCfg<128>::LDS_BYTES);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_partial_kernel<64>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, GramCfg<64>::LDS_BYTES);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_partial_kernel<64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, GramCfg<64>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_h2_kernel<128>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, GramH2Cfg<128>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_h2_kernel<64>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, GramH2Cfg<64>::LDS_BYTES);
 }
 
-hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, float* part, hipStream_t stream) {
+hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, const unsigned* amax, float* part,
+                               hipStream_t stream) {
     const int ts = gram_ts(C);
+    // fp16-piece kernel when the absmax record of f is available (32-bit buffer offsets: tensor below 4 GiB)
+    const bool h2 = amax != nullptr && ts != 0 && N * (size_t)C * 4 < 0xFFFFFF00ull;
     if (ts == 0) {
         hipLaunchKernelGGL(gram_generic_kernel, dim3(C * C), dim3(256), 0, stream, f, N, C, part);
         return hipGetLastError();
@@ -205,7 +411,13 @@ hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, floa
     const size_t chunks = (N + kp - 1) / kp;
     const size_t cps = (chunks + nsplit - 1) / nsplit;
     const size_t pix_per_split = cps * kp;
-    if (ts == 128) {
+    if (h2 && ts == 128) {
+        hipLaunchKernelGGL(gram_h2_kernel<128>, dim3(pairs * nsplit), dim3(256), GramH2Cfg<128>::LDS_BYTES, stream, f, N, C,
+                           nsplit, pix_per_split, amax, part);
+    } else if (h2) {
+        hipLaunchKernelGGL(gram_h2_kernel<64>, dim3(pairs * nsplit), dim3(256), GramH2Cfg<64>::LDS_BYTES, stream, f, N, C,
+                           nsplit, pix_per_split, amax, part);
+    } else if (ts == 128) {
         hipLaunchKernelGGL(gram_partial_kernel<128>, dim3(pairs * nsplit), dim3(256), GramCfg<128>::LDS_BYTES, stream, f,
                            N, C, nsplit, pix_per_split, part);
     } else {
@@ -229,14 +441,20 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
     const size_t CC = (size_t)C * C;
     const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const size_t e = (size_t)blockIdx.x * 32 + el;
-    float s = 0.f;
-    if (e < CC) {
-        const int i = (int)(e / C), j = (int)(e % C);
-        // tiles below the diagonal were not computed: read the mirrored element
-        size_t src = e;
-        if (ts > 0 && (i / ts) > (j / ts)) src = (size_t)j * C + i;
-        for (int k = grp; k < nslabs; k += 8) s += part[(size_t)k * CC + src];
+    const int i = (int)(e / C), j = (int)(e % C);
+    // The tiled kernels compute the tiles on or above the diagonal only, and inside a diagonal tile the fp16-piece
+    // kernel adds the two cross products of (i,j) and (j,i) in opposite orders: only elements with j >= i are read
+    // (coalesced) and each result is written to (i,j) AND (j,i), which makes G exactly symmetric.  A 32-element
+    // segment lies in one row (C % 32 == 0 for the tiled shapes); segments entirely below the diagonal do nothing.
+    const bool tri = ts > 0;
+    if (tri && (int)((size_t)blockIdx.x * 32 % C) + 31 < (int)((size_t)blockIdx.x * 32 / C)) {
+        if (threadIdx.x == 0 && mse_partial) mse_partial[blockIdx.x] = 0.0;
+        return;
     }
+    const bool mine = e < CC && (!tri || j >= i);
+    float s = 0.f;
+    if (mine)
+        for (int k = grp; k < nslabs; k += 8) s += part[(size_t)k * CC + e];
     sh[grp][el] = s;
     __syncthreads();
     if (grp == 0) {
@@ -245,19 +463,20 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
         for (int g = 1; g < 8; ++g) t += sh[g][el];
         double sq = 0.0;
         float sabs = 0.f;
-        if (e < CC) {
+        if (mine) {
+            const bool both = tri && j > i;
+            const size_t em = (size_t)j * C + i;      // the mirrored element
             const float g = t / divisor;      // torch: gram /= ch*h*w
-            if (gram_out) gram_out[e] = g;
+            if (gram_out) { gram_out[e] = g; if (both) gram_out[em] = g; }
             if (target) {
                 const float d = g - target[e];
-                sq = (double)d * (double)d;
+                sq = (double)d * (double)d * (both ? 2.0 : 1.0);
                 const float sv = coef * d;
                 sabs = fabsf(sv);
-                if (S) S[e] = sv;
+                if (S) { S[e] = sv; if (both) S[em] = sv; }
                 if (S_bf) {
                     // the same value cut into three bf16 pieces in conv_bf3's weight layout
-                    // [row i][chunk j/32][piece][j%32] (a 1x1 "conv" weight with Cout = Cin = C)
-                    const int i = (int)(e / C), j = (int)(e % C);
+                    // [row][chunk col/32][piece][col%32] (a 1x1 "conv" weight with Cout = Cin = C)
                     const unsigned uh = __float_as_uint(sv) & 0xFFFF0000u;
                     const float r1 = sv - __uint_as_float(uh);
                     const unsigned um = __float_as_uint(r1) & 0xFFFF0000u;
@@ -266,6 +485,12 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
                     S_bf[base] = (unsigned short)(uh >> 16);
                     S_bf[base + 32] = (unsigned short)(um >> 16);
                     S_bf[base + 64] = (unsigned short)(__float_as_uint(r2) >> 16);
+                    if (both) {
+                        const size_t bm = (((size_t)j * (C / 32) + i / 32) * 3) * 32 + (i & 31);
+                        S_bf[bm] = (unsigned short)(uh >> 16);
+                        S_bf[bm + 32] = (unsigned short)(um >> 16);
+                        S_bf[bm + 64] = (unsigned short)(__float_as_uint(r2) >> 16);
+                    }
                 }
             }
         }

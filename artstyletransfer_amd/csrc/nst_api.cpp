@@ -455,13 +455,14 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
     return NST_OK;
 }
 
-int gram_of(nst_ctx* ctx, const float* f_nhwc, size_t N, int C, float divisor, float* part, const float* target,
+// f_amax (nullable): absmax record of f_nhwc; with it the partial products run on the fp16 pipe
+int gram_of(nst_ctx* ctx, const float* f_nhwc, size_t N, int C, const unsigned* f_amax, float divisor, float* part, const float* target,
             float coef, float* gram_out, float* S, unsigned short* S_bf, unsigned* S_amax, double* mse_partial,
             hipStream_t s) {
     const int ns = gram_nsplit(C, N);
     {
         Timer t(ctx, s, K_GRAM, 2.0 * (double)N * C * C);
-        HIPCHK(ctx, launch_gram_partial(f_nhwc, N, C, ns, part, s));
+        HIPCHK(ctx, launch_gram_partial(f_nhwc, N, C, ns, f_amax, part, s));
     }
     Timer t(ctx, s, K_OTHER, 0);
     HIPCHK(ctx, launch_gram_finish(part, gram_nslabs(C, ns), C, divisor, target, coef, gram_out, S, S_bf, S_amax,
@@ -540,7 +541,7 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
             const size_t N = (size_t)L.acts.h[l] * L.acts.w[l];
             const double chw = (double)C * (double)N;
             const float coef = (float)((double)sw * 4.0 / (5.0 * (double)C * C * chw));
-            NSTCHK(gram_of(ctx, L.acts.act[l], N, C, (float)chw, L.gram_part, L.gram_t[q], coef, nullptr, L.S[q],
+            NSTCHK(gram_of(ctx, L.acts.act[l], N, C, h2 ? amax_act(L.acts, l) : nullptr, (float)chw, L.gram_part, L.gram_t[q], coef, nullptr, L.S[q],
                            L.S_bf[q], h2 ? amax_S(L.acts, q) : nullptr, L.style_partial[q], s));
         }
     }
@@ -856,7 +857,7 @@ int nst_level_set_targets(nst_ctx* ctx, int level, const float* content, const f
         const int l = kStyleLayer[k];
         const int C = kCout[l];
         const size_t N = (size_t)sa.h[l] * sa.w[l];
-        r = gram_of(ctx, sa.act[l], N, C, (float)((double)C * sa.h[l] * sa.w[l]), part, nullptr, 0.f, L.gram_t[k],
+        r = gram_of(ctx, sa.act[l], N, C, ctx->conv_mode == 2 ? amax_act(sa, l) : nullptr, (float)((double)C * sa.h[l] * sa.w[l]), part, nullptr, 0.f, L.gram_t[k],
                     nullptr, nullptr, nullptr, nullptr, s);
     }
     hipError_t e = hipStreamSynchronize(s);
@@ -978,7 +979,7 @@ static int closure_record(nst_ctx* ctx, const float* x, float cw, float sw, floa
             const double chw = (double)C * (double)N;
             // style = mean_k mse(G_k, Gt_k); dL/dG = sw/5 * 2 (G-Gt)/C^2; dF = 2 * dL/dG * F / (C h w)
             const float coef = (float)((double)sw * 4.0 / (5.0 * (double)C * C * chw));
-            NSTCHK(gram_of(ctx, L.acts.act[l], N, C, (float)chw, L.gram_part, L.gram_t[k], coef, nullptr, L.S[k],
+            NSTCHK(gram_of(ctx, L.acts.act[l], N, C, ctx->conv_mode == 2 ? amax_act(L.acts, l) : nullptr, (float)chw, L.gram_part, L.gram_t[k], coef, nullptr, L.S[k],
                            L.S_bf[k], ctx->conv_mode == 2 ? amax_S(L.acts, k) : nullptr, L.style_partial[k], s));
             inj[l].S = L.S[k];
             inj[l].S_bf = L.S_bf[k];
@@ -1130,14 +1131,20 @@ int nst_gram(nst_ctx* ctx, const float* f, int C, int h, int w, int normalize, f
     if (!f || !gram || C < 1 || h < 1 || w < 1) return fail(ctx, NST_E_ARG, "bad argument");
     hipStream_t s = static_cast<hipStream_t>(stream);
     const size_t N = (size_t)h * w;
-    float* nhwc = nullptr; float* part = nullptr;
+    float* nhwc = nullptr; float* part = nullptr; unsigned* amax = nullptr;
     int r = dev_alloc_t(ctx, &nhwc, N * C);
     if (r == NST_OK) r = dev_alloc_t(ctx, &part, (size_t)gram_nsplit(C, N) * C * C);
+    if (r == NST_OK && ctx->conv_mode == 2) r = dev_alloc_t(ctx, &amax, (size_t)NST_AMAX_SLOTS);
     if (r == NST_OK && launch_chw_to_hwc(f, C, h, w, nhwc, s) != hipSuccess) r = fail(ctx, NST_E_HIP, "chw_to_hwc launch failed");
+    if (r == NST_OK && amax) {
+        // the fp16-piece kernel needs the absmax of its operand (in the closure the producing conv records it)
+        if (hipMemsetAsync(amax, 0, NST_AMAX_SLOTS * 4, s) != hipSuccess || launch_absmax_slots(nhwc, N * C, amax, s) != hipSuccess)
+            r = fail(ctx, NST_E_HIP, "absmax launch failed");
+    }
     if (r == NST_OK)
-        r = gram_of(ctx, nhwc, N, C, normalize ? (float)((double)C * h * w) : 1.f, part, nullptr, 0.f, gram, nullptr, nullptr, nullptr, nullptr, s);
+        r = gram_of(ctx, nhwc, N, C, amax, normalize ? (float)((double)C * h * w) : 1.f, part, nullptr, 0.f, gram, nullptr, nullptr, nullptr, nullptr, s);
     hipError_t e = hipStreamSynchronize(s);
-    dev_free(nhwc); dev_free(part);
+    dev_free(nhwc); dev_free(part); dev_free(amax);
     if (r != NST_OK) return r;
     HIPCHK(ctx, e);
     return NST_OK;

@@ -161,7 +161,9 @@ hipError_t launch_loss_assemble(const LossAssembly& la, hipStream_t stream);
 // partial Gram of NHWC f (N pixels x C): slabs part[s][C][C] (upper-triangle tiles only)
 hipError_t gram_init_device();
 int gram_nsplit(int C, size_t N);
-hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, float* part, hipStream_t stream);
+// amax (nullable): NST_AMAX_SLOTS-word absmax record of f -> the fp16-piece kernel (3 MFMAs per product block)
+hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, const unsigned* amax, float* part,
+                               hipStream_t stream);
 // G = (sum_s part[s]) / divisor (fixed order).  If target: mse_out[0] = sum((G-Gt)^2) (double) and
 // S = coef * (G - Gt) (C x C, for the backward 1x1 conv).  gram_out / target / S / mse_partial nullable;
 // mse_partial: gram_finish_blocks(C) doubles.  `nslabs` = gram_nslabs(C, nsplit).
@@ -194,6 +196,8 @@ hipError_t launch_absmax_abssum(const float* a, size_t n, double* scratch, float
 hipError_t launch_axpy(float alpha, const float* x, float* y, size_t n, hipStream_t stream);               // y += alpha*x
 hipError_t launch_axpy_dev(const float* alpha_dev, float sign, const float* x, float* y, size_t n, hipStream_t stream);
 hipError_t launch_scale_copy(float alpha, const float* x, float* y, size_t n, hipStream_t stream);         // y = alpha*x
+hipError_t launch_add_scaled(const float* a, float alpha, const float* b, float* out, size_t n, hipStream_t stream);  // out = a + alpha*b
+hipError_t launch_copy(const float* a, float* out, size_t n, hipStream_t stream);                          // out = a (16-byte aligned)
 hipError_t launch_sub(const float* a, const float* b, float* out, size_t n, hipStream_t stream);           // out = a-b
 hipError_t launch_adam(float* x, const float* g, float* m, float* v, size_t n, float beta1, float beta2, float eps,
                        float step_size, float inv_sqrt_bc2, hipStream_t stream);

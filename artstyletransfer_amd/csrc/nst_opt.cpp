@@ -137,8 +137,7 @@ int strong_wolfe(nst_opt* o, float* x, double t, float f, float gtd, int max_ls,
     OCHK(absstats(o, o->d, s, &d_norm, &dsum));
     auto eval_at = [&](double tt, float* f_new, float* gtd_new) -> int {
         // x = x_init + t*d ; closure ; (x restored by the caller at the end)
-        OHIP(o, hipMemcpyAsync(x, o->xinit, o->n * sizeof(float), hipMemcpyDeviceToDevice, s));
-        OHIP(o, launch_axpy((float)tt, o->d, x, o->n, s));
+        OHIP(o, launch_add_scaled(o->xinit, (float)tt, o->d, x, o->n, s));
         OCHK(eval_closure(o, x, cw, sw, tvw, s, f_new));
         OCHK(dot(o, o->g, o->d, s, gtd_new));
         return NST_OK;
@@ -222,7 +221,6 @@ int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t 
     OCHK(absstats(o, o->g, s, &gmax, &gsum));
     if (gmax <= 1e-7f) { info->accepted = 0; info->t = 0.f; return NST_OK; }
     o->n_iter += 1;
-    const size_t nb = o->n * sizeof(float);
     if (o->n_iter == 1) {
         OHIP(o, launch_scale_copy(-1.f, o->g, o->d, o->n, s));   // d = -g
         for (float* p : o->old_dirs) o->spare.push_back(p);
@@ -270,7 +268,7 @@ int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t 
             OHIP(o, launch_axpy(al[i] - be, o->old_stps[i], o->d, o->n, s));
         }
     }
-    OHIP(o, hipMemcpyAsync(o->prev_g, o->g, nb, hipMemcpyDeviceToDevice, s));
+    OHIP(o, launch_copy(o->g, o->prev_g, o->n, s));
     o->have_prev = true;
     double t;
     if (o->n_iter == 1) {
@@ -283,12 +281,12 @@ int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t 
     OCHK(dot(o, o->g, o->d, s, &gtd));
     info->accepted = 0; info->t = 0.f;
     if (!(gtd > -1e-9f)) {
-        OHIP(o, hipMemcpyAsync(o->xinit, x, nb, hipMemcpyDeviceToDevice, s));
+        OHIP(o, launch_copy(x, o->xinit, o->n, s));
         LsResult r;
         OCHK(strong_wolfe(o, x, t, loss, gtd, o->max_eval - 1, cw, sw, tvw, s, &r));
         t = r.t;
-        OHIP(o, hipMemcpyAsync(x, o->xinit, nb, hipMemcpyDeviceToDevice, s));
-        if (t != 0.0) OHIP(o, launch_axpy((float)t, o->d, x, o->n, s));
+        if (t != 0.0) OHIP(o, launch_add_scaled(o->xinit, (float)t, o->d, x, o->n, s));
+        else OHIP(o, launch_copy(o->xinit, x, o->n, s));
         info->accepted = (t != 0.0) ? 1 : 0;
         info->t = (float)t;
     }
