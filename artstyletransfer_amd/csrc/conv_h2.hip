@@ -40,35 +40,47 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
-constexpr int KC = 32;            // channels per chunk
-constexpr int ROWB = 144;         // LDS row bytes: 2 pieces x 64 B + 16 B pad
-constexpr int WROWB = 128;        // global weight row bytes per (tap, cout, chunk): 2 pieces x 32 fp16
 constexpr float LO_UP = 2048.f;   // 2^11
 constexpr float LO_DOWN = 1.f / 2048.f;
 
+// KC  = channels per K chunk (32: two k-steps per stage; 16: one).
 // NTW = 32-wide output-channel tiles per wave: 2 -> 64 x 64 wave tiles (128 accumulator registers, 8 fragment
-// reads per 12 MFMAs), 1 -> 64 x 32 (64 registers, 6 reads per 6 MFMAs; for the 64-channel layers and the small
-// tiles of under-filled launches, where the bigger tile does not fit the register file next to the staging).
-// LDS: the halo patch double buffered, the per-tap weight slice triple buffered (see the main K loop).
-template <int TH, int BN, int NTW>
+//       reads per 12 MFMAs), 1 -> 64 x 32 (64 registers, 6 reads per 6 MFMAs).
+// Shapes in use:
+//   <16, 128, 2, 32>  512 threads, 16x16 pixels x 128 channels               the 128-channel-multiple layers
+//   < 8, 128, 1, 32>  512 threads,  8x16 pixels x 128 channels               their under-filled launches
+//   <16,  64, 2, 16>  256 threads, 16x16 pixels x  64 channels, 70 KB LDS    the 64-channel layers: TWO workgroups
+//                     per CU, so that one's prologue / epilogue (a large share with K = 576) runs under the other's
+//                     MFMAs; 16-channel chunks keep the double-buffered patch of each within half the LDS
+// LDS: the halo patch double buffered, the per-tap weight slice triple buffered (see the main K loop); a row holds
+// the two pieces of KC channels (2 x 2 KC bytes) + 16 B pad = 144 / 80 B, an odd multiple of 16 B: 16 consecutive
+// rows start on 16 distinct 16-B slots -> conflict-free ds_read_b128 fragments.
+template <int TH, int BN, int NTW, int KC_>
 struct H2Cfg {
+    static constexpr int KC = KC_;
+    static constexpr int KS = KC / 16;               // k-steps (MFMA K = 16) per stage
+    static constexpr int QP = KC / 4;                // 16-byte staging units per pixel (fp32) = per weight row (fp16 x 2)
+    static constexpr int PIECEB = KC * 2;            // bytes of one piece of a row
+    static constexpr int ROWB = 2 * PIECEB + 16;     // LDS row bytes
+    static constexpr int WROWB = 2 * PIECEB;         // global weight row bytes per (tap, cout, chunk)
     static constexpr int TW = 16;
     static constexpr int PH = TH + 2, PW = TW + 2;
     static constexpr int WM = TH / 4;            // waves along pixels (4 rows x 16 cols each)
     static constexpr int WN = BN / (32 * NTW);
     static constexpr int NT = 64 * WM * WN;
-    static constexpr int A_UNITS = PH * PW * (KC / 4);        // float4 units of the fp32 patch
+    static constexpr int A_UNITS = PH * PW * QP;              // float4 units of the fp32 patch
     static constexpr int A_PER_T = (A_UNITS + NT - 1) / NT;
-    static constexpr int B_UNITS = BN * (WROWB / 16);         // 16-byte units of the weight slice
+    static constexpr int B_UNITS = BN * QP;                   // 16-byte units of the weight slice
     static constexpr int B_PER_T = (B_UNITS + NT - 1) / NT;
     // patch-row pitch rounded up to a multiple of 256 B (see conv_bf3.hip)
     static constexpr int PROWB = ((PW * ROWB + 255) / 256) * 256;
     static constexpr int A_BYTES = PH * PROWB;
     static constexpr int B_BYTES = BN * ROWB;
     static constexpr int LDS_BYTES = 2 * A_BYTES + 3 * B_BYTES;
-    static_assert(NT == 512, "eight waves per workgroup");
+    static_assert(KC == 16 || KC == 32, "one or two k-steps per stage");
+    static_assert(NT == 512 || NT == 256, "eight or four waves per workgroup");
     static_assert(B_UNITS % NT == 0, "every lane stages the same number of weight units (no predication)");
-    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+    static_assert(LDS_BYTES <= (NT == 512 ? 160 : 80) * 1024, "LDS budget (two 256-thread workgroups share a CU)");
 };
 
 // Power-of-two scale that brings the recorded absmax (64 slots of non-negative float bit patterns) into
@@ -100,9 +112,10 @@ __device__ __forceinline__ void cut2x4(const f32x4 v, const float s, u32x2& hi, 
 }  // namespace
 
 // the whole workgroup program; (sp, ct) = spatial tile, output-channel tile of this workgroup
-template <int TH, int BN, int NTW>
+template <int TH, int BN, int NTW, int KC>
 __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, const int ct, const int slot_seed) {
-    using C = H2Cfg<TH, BN, NTW>;
+    using C = H2Cfg<TH, BN, NTW, KC>;
+    constexpr int ROWB = C::ROWB, WROWB = C::WROWB, QP = C::QP, PIECEB = C::PIECEB, KS = C::KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* ldsA = smem;                          // 2 patch buffers
     unsigned char* ldsB = smem + 2 * C::A_BYTES;         // 3 weight-slice buffers
@@ -130,25 +143,25 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     // past the 256-register budget, and the compiler then sinks the global loads to the end of the stage.
     auto a_lds_of = [&](int i, int to) -> int {
         const int u = to + i * C::NT;
-        const int pix = u >> 3;
+        const int pix = u / QP;
         const int pr = pix / C::PW;
         const int pc = pix - pr * C::PW;
-        return (u < C::A_UNITS) ? pr * C::PROWB + pc * ROWB + (u & 7) * 8 : -1;
+        return (u < C::A_UNITS) ? pr * C::PROWB + pc * ROWB + (u % QP) * 8 : -1;
     };
     // byte offset of patch unit i inside the image tensor; outside the image / unused: beyond the buffer (reads 0)
     auto a_voff_of = [&](int i, int to, int cin) -> unsigned {
         const int u = to + i * C::NT;
-        const int pix = u >> 3;
+        const int pix = u / QP;
         const int pr = pix / C::PW;
         const int pc = pix - pr * C::PW;
         const int gy = y0 - 1 + pr;
         const int gx = x0 - 1 + pc;
         // (unsigned compares fold the >= 0 tests; bitwise & keeps this a select instead of short-circuit branches)
         const bool ok = (u < C::A_UNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
-        return ok ? (unsigned)(((gy * p.W + gx) * cin + (u & 7) * 4) * 4) : 0xFFFFFF00u;
+        return ok ? (unsigned)(((gy * p.W + gx) * cin + (u % QP) * 4) * 4) : 0xFFFFFF00u;
     };
     auto b_ok = [&](int, int) -> bool { return true; };       // B_UNITS is a multiple of the workgroup size
-    auto b_lds_of = [&](int i, int to) -> int { const int u = to + i * C::NT; return (u >> 3) * ROWB + (u & 7) * 16; };
+    auto b_lds_of = [&](int i, int to) -> int { const int u = to + i * C::NT; return (u / QP) * ROWB + (u % QP) * 16; };
 
     // cut staged fp32 patch units [i0, i1) (held in r[0 .. i1-i0)) into two fp16 pieces, 8 bytes per piece
     auto store_a = [&](unsigned char* dstA, const float s, const f32x4* r, const int i0, const int i1, const int to) {
@@ -160,7 +173,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
                 cut2x4(r[i - i0], s, hi, lo);
                 unsigned char* row = dstA + off;
                 *reinterpret_cast<u32x2*>(row) = hi;
-                *reinterpret_cast<u32x2*>(row + 64) = lo;
+                *reinterpret_cast<u32x2*>(row + PIECEB) = lo;
             }
         }
     };
@@ -178,9 +191,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
                 u32x2 hi, lo;
                 cut2x4(__builtin_bit_cast(f32x4, rb[i]), s, hi, lo);
                 const int u = to + i * C::NT;
-                unsigned char* row = dst + (u >> 3) * ROWB + (u & 7) * 8;
+                unsigned char* row = dst + (u / QP) * ROWB + (u % QP) * 8;
                 *reinterpret_cast<u32x2*>(row) = hi;
-                *reinterpret_cast<u32x2*>(row + 64) = lo;
+                *reinterpret_cast<u32x2*>(row + PIECEB) = lo;
             }
     };
     auto opaque = [](int v) { asm volatile("" : "+v"(v)); return v; };
@@ -205,11 +218,11 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     auto request = [&](Frags& f, const unsigned char* abase, const unsigned char* bbase, const int ks) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            f.a[0][s] = *reinterpret_cast<const f16x8*>(abase + a_off0 + s * 64 + ks * 32);
-            f.a[1][s] = *reinterpret_cast<const f16x8*>(abase + a_off1 + s * 64 + ks * 32);
+            f.a[0][s] = *reinterpret_cast<const f16x8*>(abase + a_off0 + s * PIECEB + ks * 32);
+            f.a[1][s] = *reinterpret_cast<const f16x8*>(abase + a_off1 + s * PIECEB + ks * 32);
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt)
-                f.b[nt][s] = *reinterpret_cast<const f16x8*>(bbase + b_off0 + nt * 32 * ROWB + s * 64 + ks * 32);
+                f.b[nt][s] = *reinterpret_cast<const f16x8*>(bbase + b_off0 + nt * 32 * ROWB + s * PIECEB + ks * 32);
         }
     };
     auto multiply = [&](const Frags& f) {
@@ -232,7 +245,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         }
         if (MFMAS > READS) __builtin_amdgcn_sched_group_barrier(0x008, MFMAS - READS, 0);
     };
-    Frags f0, f1;
+    Frags F[2];
 
     // ---- second K source: the Gram backward dF = F S (1 tap, fp32 weights cut here).  One stage per 32-channel
     // chunk; patch and weights alternate between two LDS buffers and are staged one stage ahead (global loads two
@@ -250,7 +263,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
 #pragma unroll
         for (int i = 0; i < C::B_PER_T; ++i) {
             const int u = tid + i * C::NT;
-            b_voff[i] = b_ok(i, tid) ? (unsigned)(((u >> 3) * cin + (u & 7) * 4) * 4) : 0xFFFFFF00u;
+            b_voff[i] = b_ok(i, tid) ? (unsigned)(((u / QP) * cin + (u % QP) * 4) * 4) : 0xFFFFFF00u;
         }
         auto load = [&](int chunk) {
 #pragma unroll
@@ -275,13 +288,10 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             }
             const unsigned char* centre = ldsA + cb * C::A_BYTES + C::PROWB + ROWB;     // 1 tap: the centre of the patch
             const unsigned char* bcur = ldsB + cb * C::B_BYTES;
-            request(f0, centre, bcur, 0);
-            request(f1, centre, bcur, 1);
-            multiply(f0);
-            multiply(f1);
-            __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
-            pin_kstep();
-            __builtin_amdgcn_sched_group_barrier(0x008, MFMAS, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) request(F[ks], centre, bcur, ks);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) multiply(F[ks]);
             __syncthreads();
         }
     };
@@ -311,7 +321,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
 #pragma unroll
             for (int i = 0; i < C::B_PER_T; ++i) {
                 const int u = to + i * C::NT;
-                const unsigned voff = b_ok(i, to) ? (unsigned)((u >> 3) * nch * WROWB + (u & 7) * 16) : 0xFFFFFF00u;
+                const unsigned voff = b_ok(i, to) ? (unsigned)((u / QP) * nch * WROWB + (u % QP) * 16) : 0xFFFFFF00u;
                 r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, voff, soff, 0);
             }
         };
@@ -330,9 +340,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             store_b(ldsB + C::B_BYTES, r1, tid);
         }
         __syncthreads();
-        request(f0, ldsA + tap_off(0), ldsB, 0);
+        request(F[0], ldsA + tap_off(0), ldsB, 0);
 
-        for (int c = 0; c < nch; ++c) {
+        // one chunk = 9 stages; PAR = which fragment set holds the operands of its first k-step (alternates per
+        // stage when a stage is a single k-step, so chunks are then processed in pairs)
+        auto chunk = [&](const int c, auto par_c) {
+            constexpr int PAR = decltype(par_c)::value;
             unsigned char* acur = ldsA + (c & 1) * C::A_BYTES;
             unsigned char* anext = ldsA + ((c + 1) & 1) * C::A_BYTES;
             // The stage body is branch-free so that the compiler's s_waitcnt counts stay exact (a vmcnt merged over
@@ -355,16 +368,32 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
                 if (t == 3) store_a(anext, sa, ra, 0, AH, to);
                 if (t == 7) store_a(anext, sa, ra, AH, C::A_PER_T, to);
                 const unsigned char* bcur = ldsB + (t % 3) * C::B_BYTES;
-                // k-step 0
-                request(f1, acur + tap_off(t), bcur, 1);
-                multiply(f0);
-                pin_kstep();
-                // k-step 1, fetching the first fragments of the next stage
-                if (t + 1 < 9) request(f0, acur + tap_off(t + 1), ldsB + ((t + 1) % 3) * C::B_BYTES, 0);
-                else request(f0, anext + tap_off(0), ldsB, 0);
-                multiply(f1);
-                pin_kstep();
+                const unsigned char* anxt = (t + 1 < 9) ? acur + tap_off(t + 1) : anext + tap_off(0);
+                const unsigned char* bnxt = ldsB + ((t + 1) % 3) * C::B_BYTES;
+                if (KS == 2) {
+                    // k-step 0, fetching k-step 1; then k-step 1, fetching the first fragments of the next stage
+                    request(F[1], acur + tap_off(t), bcur, 1);
+                    multiply(F[0]);
+                    pin_kstep();
+                    request(F[0], anxt, bnxt, 0);
+                    multiply(F[1]);
+                    pin_kstep();
+                } else {
+                    const int cur = (PAR + t) & 1;      // a constant once the tap loop is unrolled
+                    request(F[cur ^ 1], anxt, bnxt, 0);
+                    multiply(F[cur]);
+                    pin_kstep();
+                }
                 __syncthreads();
+            }
+        };
+        if (KS == 2) {
+            for (int c = 0; c < nch; ++c) chunk(c, std::integral_constant<int, 0>{});
+        } else {
+            // 9 stages per chunk: the fragment sets swap roles from one chunk to the next (nch is even)
+            for (int c = 0; c < nch; c += 2) {
+                chunk(c, std::integral_constant<int, 0>{});
+                chunk(c + 1, std::integral_constant<int, 1>{});
             }
         }
     };
@@ -453,15 +482,15 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     }
 }
 
-template <int TH, int BN, int NTW>
-__global__ __launch_bounds__(512, 2) void conv_h2_kernel(ConvParams p) {
+template <int TH, int BN, int NTW, int KC>
+__global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_kernel(ConvParams p) {
     const int n_ct = p.Cout / BN;
-    conv_h2_body<TH, BN, NTW>(p, blockIdx.x / n_ct, blockIdx.x % n_ct, blockIdx.x);
+    conv_h2_body<TH, BN, NTW, KC>(p, blockIdx.x / n_ct, blockIdx.x % n_ct, blockIdx.x);
 }
 
 // One launch = one layer over several images (the pyramid levels of a closure), see conv_bf3.hip.
-template <int TH, int BN, int NTW>
-__global__ __launch_bounds__(512, 2) void conv_h2_batch_kernel(ConvBatch b) {
+template <int TH, int BN, int NTW, int KC>
+__global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_batch_kernel(ConvBatch b) {
     const int n_ct = b.Cout / BN;
     const int sp_all = blockIdx.x / n_ct;
     int i = 0;
@@ -475,23 +504,23 @@ __global__ __launch_bounds__(512, 2) void conv_h2_batch_kernel(ConvBatch b) {
     p.pool_out = im.pool_out;
     p.wt_h2 = b.wt_h2; p.wt_h2_inv = b.wt_h2_inv; p.wt2_f32 = im.wt2_f32;
     p.amax_in = im.amax_in; p.amax_in2 = im.amax_in2; p.amax_w2 = im.amax_w2; p.amax_out = im.amax_out;
-    conv_h2_body<TH, BN, NTW>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), blockIdx.x % n_ct, blockIdx.x);
+    conv_h2_body<TH, BN, NTW, KC>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), blockIdx.x % n_ct, blockIdx.x);
 }
 
-template <int TH, int BN, int NTW>
+template <int TH, int BN, int NTW, int KC>
 static hipError_t init_one() {
-    constexpr int lds = H2Cfg<TH, BN, NTW>::LDS_BYTES;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_kernel<TH, BN, NTW>),
+    constexpr int lds = H2Cfg<TH, BN, NTW, KC>::LDS_BYTES;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_kernel<TH, BN, NTW, KC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_batch_kernel<TH, BN, NTW>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_batch_kernel<TH, BN, NTW, KC>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 hipError_t conv_h2_init_device() {
-    hipError_t e = init_one<16, 128, 2>();
-    if (e == hipSuccess) e = init_one<8, 128, 1>();
-    if (e == hipSuccess) e = init_one<16, 64, 1>();
+    hipError_t e = init_one<16, 128, 2, 32>();
+    if (e == hipSuccess) e = init_one<8, 128, 1, 32>();
+    if (e == hipSuccess) e = init_one<16, 64, 2, 16>();
     return e;
 }
 
@@ -501,17 +530,17 @@ static int h2_tile_rows(int Cout, long blocks16) {
     return blocks16 < 400 ? 8 : 16;
 }
 
-template <int TH, int BN, int NTW>
+template <int TH, int BN, int NTW, int KC>
 static void launch_batch_cfg(const ConvBatch& b, int blocks, hipStream_t stream) {
-    constexpr int lds = H2Cfg<TH, BN, NTW>::LDS_BYTES;
-    constexpr int nt = H2Cfg<TH, BN, NTW>::NT;
-    hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW>), dim3(blocks), dim3(nt), lds, stream, b);
+    constexpr int lds = H2Cfg<TH, BN, NTW, KC>::LDS_BYTES;
+    constexpr int nt = H2Cfg<TH, BN, NTW, KC>::NT;
+    hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC>), dim3(blocks), dim3(nt), lds, stream, b);
 }
-template <int TH, int BN, int NTW>
+template <int TH, int BN, int NTW, int KC>
 static void launch_single_cfg(const ConvParams& p, int blocks, hipStream_t stream) {
-    constexpr int lds = H2Cfg<TH, BN, NTW>::LDS_BYTES;
-    constexpr int nt = H2Cfg<TH, BN, NTW>::NT;
-    hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW>), dim3(blocks), dim3(nt), lds, stream, p);
+    constexpr int lds = H2Cfg<TH, BN, NTW, KC>::LDS_BYTES;
+    constexpr int nt = H2Cfg<TH, BN, NTW, KC>::NT;
+    hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW, KC>), dim3(blocks), dim3(nt), lds, stream, p);
 }
 
 static bool h2_operands_ok(const void* wt, const unsigned* amax_in, int Cin, int Cout, const float* in2, const float* wt2,
@@ -542,9 +571,9 @@ hipError_t launch_conv_h2_batch(const ConvBatch& b0, hipStream_t stream) {
         b.img[i].tile_end = tiles;
     }
     const int blocks = tiles * (b.Cout / bn);
-    if (!wide) launch_batch_cfg<16, 64, 1>(b, blocks, stream);
-    else if (th == 8) launch_batch_cfg<8, 128, 1>(b, blocks, stream);
-    else launch_batch_cfg<16, 128, 2>(b, blocks, stream);
+    if (!wide) launch_batch_cfg<16, 64, 2, 16>(b, blocks, stream);
+    else if (th == 8) launch_batch_cfg<8, 128, 1, 32>(b, blocks, stream);
+    else launch_batch_cfg<16, 128, 2, 32>(b, blocks, stream);
     return hipGetLastError();
 }
 
@@ -561,9 +590,9 @@ hipError_t launch_conv_h2(const ConvParams& p0, hipStream_t stream) {
     p.tiles_x = (p.W + 15) / 16;
     p.tiles_y = (p.H + th - 1) / th;
     const int blocks = p.tiles_x * p.tiles_y * (p.Cout / bn);
-    if (!wide) launch_single_cfg<16, 64, 1>(p, blocks, stream);
-    else if (th == 8) launch_single_cfg<8, 128, 1>(p, blocks, stream);
-    else launch_single_cfg<16, 128, 2>(p, blocks, stream);
+    if (!wide) launch_single_cfg<16, 64, 2, 16>(p, blocks, stream);
+    else if (th == 8) launch_single_cfg<8, 128, 1, 32>(p, blocks, stream);
+    else launch_single_cfg<16, 128, 2, 32>(p, blocks, stream);
     return hipGetLastError();
 }
 

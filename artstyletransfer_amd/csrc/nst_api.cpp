@@ -238,9 +238,12 @@ void make_bf3(const float* w, int taps, int rows, int K, std::vector<uint16_t>& 
             }
 }
 
-// w: [taps][rows][K] fp32  ->  out: [taps][rows][K/32][2][32] fp16 pieces of w * s, s = the power of two that
-// brings the largest |w| into [2^14, 2^15); *inv = 1 / s (same cut as conv_h2.hip::cut2x4)
+// w: [taps][rows][K] fp32  ->  out: [taps][rows][K/kc][2][kc] fp16 pieces of w * s, s = the power of two that
+// brings the largest |w| into [2^14, 2^15); *inv = 1 / s (same cut as conv_h2.hip::cut2x4).  kc = channels per K
+// chunk of the kernel shape that consumes these weights: 32 when `rows` (its output channels) is a multiple of
+// 128, else 16 (conv_h2.hip, shapes in use).
 void make_h2(const float* w, int taps, int rows, int K, std::vector<uint16_t>& out, float* inv) {
+    const int kc = (rows % 128 == 0) ? 32 : 16;
     const size_t n = (size_t)taps * rows * K;
     float mx = 0.f;
     for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));
@@ -248,8 +251,8 @@ void make_h2(const float* w, int taps, int rows, int K, std::vector<uint16_t>& o
     if (mx > 0.f) (void)std::frexp(mx, &ex);          // mx = f * 2^ex, f in [0.5, 1)
     const float s = std::ldexp(1.f, 15 - ex);          // mx * s in [2^14, 2^15)
     *inv = std::ldexp(1.f, ex - 15);
-    const int nch = K / 32;
-    out.assign((size_t)taps * rows * nch * 64, 0);
+    const int nch = K / kc;
+    out.assign((size_t)taps * rows * nch * 2 * kc, 0);
     for (int t = 0; t < taps; ++t)
         for (int r = 0; r < rows; ++r)
             for (int k = 0; k < K; ++k) {
@@ -258,8 +261,8 @@ void make_h2(const float* w, int taps, int rows, int K, std::vector<uint16_t>& o
                 const _Float16 lo = (_Float16)((x - (float)hi) * 2048.f);
                 uint16_t uh, ul;
                 std::memcpy(&uh, &hi, 2); std::memcpy(&ul, &lo, 2);
-                const size_t base = (((size_t)t * rows + r) * nch + k / 32) * 64 + (k % 32);
-                out[base] = uh; out[base + 32] = ul;
+                const size_t base = (((size_t)t * rows + r) * nch + k / kc) * 2 * kc + (k % kc);
+                out[base] = uh; out[base + kc] = ul;
             }
 }
 
