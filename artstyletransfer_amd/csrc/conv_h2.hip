@@ -112,7 +112,7 @@ __device__ __forceinline__ void cut2x4(const f32x4 v, const float s, u32x2& hi, 
 }  // namespace
 
 // the whole workgroup program; (sp, ct) = spatial tile, output-channel tile of this workgroup
-template <int TH, int BN, int NTW, int KC>
+template <int TH, int BN, int NTW, int KC, bool UNPOOL>
 __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, const int ct, const int slot_seed) {
     using C = H2Cfg<TH, BN, NTW, KC>;
     constexpr int ROWB = C::ROWB, WROWB = C::WROWB, QP = C::QP, PIECEB = C::PIECEB, KS = C::KS;
@@ -148,8 +148,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         const int pc = pix - pr * C::PW;
         return (u < C::A_UNITS) ? pr * C::PROWB + pc * ROWB + (u % QP) * 8 : -1;
     };
-    // byte offset of patch unit i inside the image tensor; outside the image / unused: beyond the buffer (reads 0)
-    auto a_voff_of = [&](int i, int to, int cin) -> unsigned {
+    // byte offset of patch unit i inside the image tensor; outside the image / unused: beyond the buffer (reads 0).
+    // `pooled`: the tensor is the 2x2-pooled map (H/2 x W/2) and pixel (gy, gx) reads its window's element.
+    auto a_voff_of = [&](int i, int to, int cin, const bool pooled) -> unsigned {
         const int u = to + i * C::NT;
         const int pix = u / QP;
         const int pr = pix / C::PW;
@@ -157,20 +158,45 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         const int gy = y0 - 1 + pr;
         const int gx = x0 - 1 + pc;
         // (unsigned compares fold the >= 0 tests; bitwise & keeps this a select instead of short-circuit branches)
-        const bool ok = (u < C::A_UNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
-        return ok ? (unsigned)(((gy * p.W + gx) * cin + (u % QP) * 4) * 4) : 0xFFFFFF00u;
+        bool ok = (u < C::A_UNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+        if (!pooled) return ok ? (unsigned)(((gy * p.W + gx) * cin + (u % QP) * 4) * 4) : 0xFFFFFF00u;
+        const int PH2 = p.H >> 1, PW2 = p.W >> 1;
+        ok = ok & ((gy >> 1) < PH2) & ((gx >> 1) < PW2);      // the odd last row / column belongs to no window
+        return ok ? (unsigned)((((gy >> 1) * PW2 + (gx >> 1)) * cin + (u % QP) * 4) * 4) : 0xFFFFFF00u;
+    };
+    // byte offset of the arg-max code word of patch unit i: [pooled pixel][32-channel group][window position]
+    auto a_coff_of = [&](int i, int to, int cin) -> unsigned {
+        const int u = to + i * C::NT;
+        const int pix = u / QP;
+        const int pr = pix / C::PW;
+        const int pc = pix - pr * C::PW;
+        const int gy = y0 - 1 + pr;
+        const int gx = x0 - 1 + pc;
+        const int PH2 = p.H >> 1, PW2 = p.W >> 1;
+        const bool ok = (u < C::A_UNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W) &
+                        ((gy >> 1) < PH2) & ((gx >> 1) < PW2);
+        return ok ? (unsigned)(((((gy >> 1) * PW2 + (gx >> 1)) * (cin >> 5)) * 4 + (gy & 1) * 2 + (gx & 1)) * 4) : 0xFFFFFF00u;
     };
     auto b_ok = [&](int, int) -> bool { return true; };       // B_UNITS is a multiple of the workgroup size
     auto b_lds_of = [&](int i, int to) -> int { const int u = to + i * C::NT; return (u / QP) * ROWB + (u % QP) * 16; };
 
     // cut staged fp32 patch units [i0, i1) (held in r[0 .. i1-i0)) into two fp16 pieces, 8 bytes per piece
-    auto store_a = [&](unsigned char* dstA, const float s, const f32x4* r, const int i0, const int i1, const int to) {
+    // `code` (UNPOOL launches of the main source): r holds the POOLED gradient; element k of unit (pixel, q) survives
+    // where bit (bit0 + 4 q + k) of its code word says that this pixel was its window's first positive maximum
+    auto store_a = [&](unsigned char* dstA, const float s, const f32x4* r, const int i0, const int i1, const int to,
+                       const unsigned* code = nullptr, const int bit0 = 0) {
 #pragma unroll
         for (int i = i0; i < i1; ++i) {
             const int off = a_lds_of(i, to);
             if (off >= 0) {
                 u32x2 hi, lo;
-                cut2x4(r[i - i0], s, hi, lo);
+                f32x4 v = r[i - i0];
+                if (code) {
+                    const unsigned bits = code[i - i0] >> (bit0 + ((to + i * C::NT) % QP) * 4);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] = ((bits >> k) & 1u) ? v[k] : 0.f;
+                }
+                cut2x4(v, s, hi, lo);
                 unsigned char* row = dstA + off;
                 *reinterpret_cast<u32x2*>(row) = hi;
                 *reinterpret_cast<u32x2*>(row + PIECEB) = lo;
@@ -259,7 +285,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             const_cast<float*>(wts), 0, (unsigned)((size_t)p.Cout * cin * 4), 0x00020000);
         unsigned a_voff[C::A_PER_T], b_voff[C::B_PER_T];
 #pragma unroll
-        for (int i = 0; i < C::A_PER_T; ++i) a_voff[i] = a_voff_of(i, tid, cin);
+        for (int i = 0; i < C::A_PER_T; ++i) a_voff[i] = a_voff_of(i, tid, cin, false);
 #pragma unroll
         for (int i = 0; i < C::B_PER_T; ++i) {
             const int u = tid + i * C::NT;
@@ -305,16 +331,25 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     //     multiplies - every wave leaves the barrier with its next operands in registers.
     auto main_source = [&](const float* src, const int cin, const void* wts, const float sa) {
         const int nch = cin / KC;
+        const size_t in_px = UNPOOL ? (size_t)(p.H >> 1) * (p.W >> 1) : (size_t)p.H * p.W;
         const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(src), 0, (unsigned)((size_t)p.H * p.W * cin * 4), 0x00020000);
+            const_cast<float*>(src), 0, (unsigned)(in_px * cin * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<void*>(wts), 0, (unsigned)((size_t)9 * p.Cout * nch * WROWB), 0x00020000);
-        // patch units [i0, i1) of a chunk -> r[0 .. i1-i0)
+        const __amdgpu_buffer_rsrc_t rsrc_code = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<unsigned*>(UNPOOL ? p.pcode_in : nullptr), 0, UNPOOL ? (unsigned)(in_px * (cin >> 5) * 16) : 0u, 0x00020000);
+        unsigned rc[UNPOOL ? C::A_PER_T : 1];
+        // patch units [i0, i1) of a chunk -> r[0 .. i1-i0) (+ their arg-max code words when un-pooling)
         auto load_a = [&](f32x4* r, int chunk, const int i0, const int i1, const int to) {
 #pragma unroll
-            for (int i = i0; i < i1; ++i)
-                r[i - i0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, a_voff_of(i, to, cin), chunk * KC * 4, 0));
+            for (int i = i0; i < i1; ++i) {
+                r[i - i0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, a_voff_of(i, to, cin, UNPOOL), chunk * KC * 4, 0));
+                if (UNPOOL)
+                    rc[i - i0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_code, a_coff_of(i, to, cin), ((chunk * KC) >> 5) * 16, 0);
+            }
         };
+        // first code bit of a chunk inside its 32-channel word
+        auto bit0_of = [&](int chunk) { return (chunk * KC) & 31; };
         // pre-cut weights: [tap][Cout][chunk][piece][32] fp16, i.e. 128 contiguous bytes per (tap, cout, chunk)
         auto load_b = [&](u32x4 (&r)[C::B_PER_T], int chunk, int tap, const int to) {
             const int soff = ((tap * p.Cout + n0) * nch + chunk) * WROWB;
@@ -335,7 +370,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             load_b(r1, 0, 1, tid);
             load_b(rb, 0, 2, tid);
             __syncthreads();          // the previous source is done with the LDS buffers
-            store_a(ldsA, sa, ra, 0, C::A_PER_T, tid);
+            store_a(ldsA, sa, ra, 0, C::A_PER_T, tid, UNPOOL ? rc : nullptr, bit0_of(0));
             store_b(ldsB, r0, tid);
             store_b(ldsB + C::B_BYTES, r1, tid);
         }
@@ -365,8 +400,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
                 // keep the loads HERE: left free, the scheduler sinks them towards the end of the stage (their
                 // registers are then shared with the fragments) and the next stage stalls on them
                 __builtin_amdgcn_sched_barrier(0);
-                if (t == 3) store_a(anext, sa, ra, 0, AH, to);
-                if (t == 7) store_a(anext, sa, ra, AH, C::A_PER_T, to);
+                if (t == 3) store_a(anext, sa, ra, 0, AH, to, UNPOOL ? rc : nullptr, bit0_of(cn));
+                if (t == 7) store_a(anext, sa, ra, AH, C::A_PER_T, to, UNPOOL ? rc : nullptr, bit0_of(cn));
                 const unsigned char* bcur = ldsB + (t % 3) * C::B_BYTES;
                 const unsigned char* anxt = (t + 1 < 9) ? acur + tap_off(t + 1) : anext + tap_off(0);
                 const unsigned char* bnxt = ldsB + ((t + 1) % 3) * C::B_BYTES;
@@ -422,6 +457,133 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     // epilogue: D[m][n]: n = lane&31, m = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int words = p.Cout >> 5;          // ReLU bit-mask words per pixel
     float amax = 0.f;
+    auto record_amax = [&]() {
+        if (p.amax_out) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+            if (lane == 0) atomicMax(p.amax_out + ((slot_seed * (C::NT / 64) + wave) & (NST_AMAX_SLOTS - 1)), __float_as_uint(amax));
+        }
+    };
+
+    // ---- fast epilogue: a tile that lies inside the image (every tile when H, W are multiples of 16).  No bounds
+    // tests; every access is a buffer instruction = per-lane byte offset fixed for the whole epilogue + a scalar
+    // offset per element (SALU arithmetic), so the ~100 instructions per element of the general form below (64-bit
+    // indices, bounds, per-element option branches) shrink to ~10.  With K = 576 the general epilogue was a third
+    // of a workgroup's time.
+    const bool interior = (y0 + TH <= p.H) && (x0 + C::TW <= p.W);
+    const bool fwd_like = !p.bits_in && !p.addend;
+    const bool bwd_like = p.bits_in && !p.bits_out && !p.pool_out && !p.pcode_out;
+    if (interior && !p.mask && (fwd_like || bwd_like) && (size_t)p.H * p.W * p.Cout * 4 < 0xFFFFFF00ull) {
+        const unsigned out_bytes = (unsigned)((size_t)p.H * p.W * p.Cout * 4);
+        const unsigned bit_bytes = (unsigned)((size_t)p.H * p.W * words * 4);
+        const int colB = p.Cout * 4, rowB = p.W * colB;              // bytes per pixel / per image row
+        const int wcolB = words * 4, wrowB = p.W * wcolB;            // the same for the bit-mask words
+        const int pix0 = (y0 + wm * 4) * p.W + x0 + 4 * half;        // this lane's first pixel
+        const int cg0 = n0 + wn * 32 * NTW;                          // this wave's first output channel
+        const unsigned vbase = (unsigned)(pix0 * colB + (cg0 + l31) * 4);
+        const unsigned wbase = (unsigned)(pix0 * wcolB + (cg0 >> 5) * 4);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
+        // (mt, r) -> scalar offsets of the element's pixel: row (r >> 3) + 2 mt, column (r & 3) + 8 ((r >> 2) & 1)
+        auto soff = [&](int mt, int r, int rb, int cb) { return ((r >> 3) + 2 * mt) * rb + ((r & 3) + 8 * ((r >> 2) & 1)) * cb; };
+        if (bwd_like) {
+            const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.bits_in), 0, bit_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.addend), 0, p.addend ? out_bytes : 0u, 0x00020000);
+            const float lo_clamp = p.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const float bv = p.bias ? p.bias[cg0 + nt * 32 + l31] : 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                    for (int r0 = 0; r0 < 16; r0 += 8) {
+                        unsigned wv[8];
+                        float ad[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {          // the loads of eight elements first, then their arithmetic
+                            const int r = r0 + k;
+                            wv[k] = __builtin_amdgcn_raw_buffer_load_b32(rs_bits, wbase, soff(mt, r, wrowB, wcolB) + nt * 4, 0);
+                            ad[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, vbase, soff(mt, r, rowB, colB) + nt * 128, 0));
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            const int r = r0 + k;
+                            float v = fmaf(accx[mt][nt][r], LO_DOWN, accm[mt][nt][r]) * inv + bv;
+                            v = fmaxf(v + ad[k], lo_clamp);          // an absent addend reads as zeros
+                            v = ((wv[k] >> l31) & 1u) ? v : 0.f;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, vbase, soff(mt, r, rowB, colB) + nt * 128, 0);
+                            amax = fmaxf(amax, fabsf(v));
+                        }
+                    }
+                }
+            }
+        } else {
+            const int PW2 = p.W >> 1;
+            const unsigned pool_bytes = (unsigned)((size_t)(p.H >> 1) * PW2 * p.Cout * 4);
+            const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(p.bits_out, 0, p.bits_out ? bit_bytes : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc(p.pool_out, 0, p.pool_out ? pool_bytes : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_code = __builtin_amdgcn_make_buffer_rsrc(
+                p.pcode_out, 0, p.pcode_out ? (unsigned)((size_t)(p.H >> 1) * PW2 * words * 16) : 0u, 0x00020000);
+            // one lane per half-wave writes the bit words; the others carry an offset beyond the buffer (dropped)
+            const unsigned wlane = (l31 == 0) ? wbase : 0xFFFFFF00u;
+            const int ppix0 = ((y0 + wm * 4) >> 1) * PW2 + ((x0 + 4 * half) >> 1);
+            const unsigned pbase = (unsigned)(ppix0 * colB + (cg0 + l31) * 4);
+            const unsigned cbase = (l31 == 0) ? (unsigned)((ppix0 * words + (cg0 >> 5)) * 16) : 0xFFFFFF00u;
+            const float lo_clamp = p.relu ? 0.f : -__builtin_inff();
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) {
+                const float bv = p.bias ? p.bias[cg0 + nt * 32 + l31] : 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float v = fmaf(accx[mt][nt][r], LO_DOWN, accm[mt][nt][r]) * inv + bv;
+                        v = fmaxf(v, lo_clamp);
+                        accm[mt][nt][r] = v;
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, vbase, soff(mt, r, rowB, colB) + nt * 128, 0);
+                        amax = fmaxf(amax, fabsf(v));
+                        if (p.bits_out) {
+                            // ReLU mask of this output for the backward pass: bit = lane, one word per half-wave
+                            const unsigned long long bal = __ballot(v > 0.f);
+                            __builtin_amdgcn_raw_buffer_store_b32(half ? (unsigned)(bal >> 32) : (unsigned)bal, rs_bits, wlane,
+                                                                  soff(mt, r, wrowB, wcolB) + nt * 4, 0);
+                        }
+                    }
+                    if (p.pool_out) {
+                        // 2x2/2 max pool of the tile rows (2 mt, 2 mt + 1): the four window elements sit in this lane's
+                        // registers r, r+1, r+8, r+9; window column of r = 2 j: {0, 1, 4, 5}[j] (+ 2 per half-wave)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int r = 2 * j;
+                            const int pcol = (j & 1) + 4 * (j >> 1);
+                            const float mx = fmaxf(fmaxf(accm[mt][nt][r], accm[mt][nt][r + 1]),
+                                                   fmaxf(accm[mt][nt][r + 8], accm[mt][nt][r + 9]));
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mx), rs_pool, pbase,
+                                                                  (mt * PW2 + pcol) * colB + nt * 128, 0);
+                            if (p.pcode_out) {
+                                // arg-max code for the un-pooling loader (see the general form below)
+                                int pos = 0;
+                                float best = accm[mt][nt][r];
+                                if (accm[mt][nt][r + 1] > best) { best = accm[mt][nt][r + 1]; pos = 1; }
+                                if (accm[mt][nt][r + 8] > best) { best = accm[mt][nt][r + 8]; pos = 2; }
+                                if (accm[mt][nt][r + 9] > best) { best = accm[mt][nt][r + 9]; pos = 3; }
+                                const bool live = best > 0.f;
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const unsigned long long bal = __ballot(live && pos == q);
+                                    __builtin_amdgcn_raw_buffer_store_b32(half ? (unsigned)(bal >> 32) : (unsigned)bal, rs_code, cbase,
+                                                                          ((mt * PW2 + pcol) * words + nt) * 16 + q * 4, 0);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        record_amax();
+        return;
+    }
+
+    // ---- general epilogue (edge tiles, fp32 masks, tensors from 4 GiB up)
 #pragma unroll
     for (int nt = 0; nt < NTW; ++nt) {
         const int co = n0 + wn * 32 * NTW + nt * 32 + l31;
@@ -470,26 +632,40 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
                                            fmaxf(accm[mt][nt][r + 8], accm[mt][nt][r + 9]));
                     const int mcol = (r & 3) + 8 * (r >> 2) + 4 * half;      // column of register r (row 0 of the pair)
                     const int px = (x0 + mcol) >> 1;
-                    if (py < PH2 && px < PW2) p.pool_out[((size_t)py * PW2 + px) * p.Cout + co] = mx;
+                    const bool inw = (py < PH2 && px < PW2);
+                    if (inw) p.pool_out[((size_t)py * PW2 + px) * p.Cout + co] = mx;
+                    if (p.pcode_out) {
+                        // arg-max code for the un-pooling input-gradient loader: one word per window position, bit =
+                        // channel & 31, set where that position holds the window's FIRST maximum and it is positive
+                        // (max_pool2d backward + the ReLU mask of the pooled activation)
+                        int pos = 0;
+                        float best = accm[mt][nt][r];
+                        if (accm[mt][nt][r + 1] > best) { best = accm[mt][nt][r + 1]; pos = 1; }
+                        if (accm[mt][nt][r + 8] > best) { best = accm[mt][nt][r + 8]; pos = 2; }
+                        if (accm[mt][nt][r + 9] > best) { best = accm[mt][nt][r + 9]; pos = 3; }
+                        const bool live = best > 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const unsigned long long bal = __ballot(live && pos == q);
+                            if (l31 == 0 && inw)
+                                p.pcode_out[(((size_t)py * PW2 + px) * words + cw) * 4 + q] = half ? (unsigned)(bal >> 32) : (unsigned)bal;
+                        }
+                    }
                 }
             }
         }
     }
-    if (p.amax_out) {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-        if (lane == 0) atomicMax(p.amax_out + ((slot_seed * (C::NT / 64) + wave) & (NST_AMAX_SLOTS - 1)), __float_as_uint(amax));
-    }
+    record_amax();
 }
 
-template <int TH, int BN, int NTW, int KC>
+template <int TH, int BN, int NTW, int KC, bool UNPOOL>
 __global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_kernel(ConvParams p) {
     const int n_ct = p.Cout / BN;
-    conv_h2_body<TH, BN, NTW, KC>(p, blockIdx.x / n_ct, blockIdx.x % n_ct, blockIdx.x);
+    conv_h2_body<TH, BN, NTW, KC, UNPOOL>(p, blockIdx.x / n_ct, blockIdx.x % n_ct, blockIdx.x);
 }
 
 // One launch = one layer over several images (the pyramid levels of a closure), see conv_bf3.hip.
-template <int TH, int BN, int NTW, int KC>
+template <int TH, int BN, int NTW, int KC, bool UNPOOL>
 __global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_batch_kernel(ConvBatch b) {
     const int n_ct = b.Cout / BN;
     const int sp_all = blockIdx.x / n_ct;
@@ -504,23 +680,27 @@ __global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_batch
     p.pool_out = im.pool_out;
     p.wt_h2 = b.wt_h2; p.wt_h2_inv = b.wt_h2_inv; p.wt2_f32 = im.wt2_f32;
     p.amax_in = im.amax_in; p.amax_in2 = im.amax_in2; p.amax_w2 = im.amax_w2; p.amax_out = im.amax_out;
-    conv_h2_body<TH, BN, NTW, KC>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), blockIdx.x % n_ct, blockIdx.x);
+    p.pcode_in = im.pcode_in; p.pcode_out = im.pcode_out;
+    conv_h2_body<TH, BN, NTW, KC, UNPOOL>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), blockIdx.x % n_ct, blockIdx.x);
 }
 
-template <int TH, int BN, int NTW, int KC>
+template <int TH, int BN, int NTW, int KC, bool UNPOOL>
 static hipError_t init_one() {
     constexpr int lds = H2Cfg<TH, BN, NTW, KC>::LDS_BYTES;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_kernel<TH, BN, NTW, KC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_kernel<TH, BN, NTW, KC, UNPOOL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_batch_kernel<TH, BN, NTW, KC>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_batch_kernel<TH, BN, NTW, KC, UNPOOL>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 }
 
 hipError_t conv_h2_init_device() {
-    hipError_t e = init_one<16, 128, 2, 32>();
-    if (e == hipSuccess) e = init_one<8, 128, 1, 32>();
-    if (e == hipSuccess) e = init_one<16, 64, 2, 16>();
+    hipError_t e = init_one<16, 128, 2, 32, false>();
+    if (e == hipSuccess) e = init_one<8, 128, 1, 32, false>();
+    if (e == hipSuccess) e = init_one<16, 64, 2, 16, false>();
+    if (e == hipSuccess) e = init_one<16, 128, 2, 32, true>();
+    if (e == hipSuccess) e = init_one<8, 128, 1, 32, true>();
+    if (e == hipSuccess) e = init_one<16, 64, 2, 16, true>();
     return e;
 }
 
@@ -534,13 +714,15 @@ template <int TH, int BN, int NTW, int KC>
 static void launch_batch_cfg(const ConvBatch& b, int blocks, hipStream_t stream) {
     constexpr int lds = H2Cfg<TH, BN, NTW, KC>::LDS_BYTES;
     constexpr int nt = H2Cfg<TH, BN, NTW, KC>::NT;
-    hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC>), dim3(blocks), dim3(nt), lds, stream, b);
+    if (b.unpool) hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, true>), dim3(blocks), dim3(nt), lds, stream, b);
+    else hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, false>), dim3(blocks), dim3(nt), lds, stream, b);
 }
 template <int TH, int BN, int NTW, int KC>
 static void launch_single_cfg(const ConvParams& p, int blocks, hipStream_t stream) {
     constexpr int lds = H2Cfg<TH, BN, NTW, KC>::LDS_BYTES;
     constexpr int nt = H2Cfg<TH, BN, NTW, KC>::NT;
-    hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW, KC>), dim3(blocks), dim3(nt), lds, stream, p);
+    if (p.pcode_in) hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW, KC, true>), dim3(blocks), dim3(nt), lds, stream, p);
+    else hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW, KC, false>), dim3(blocks), dim3(nt), lds, stream, p);
 }
 
 static bool h2_operands_ok(const void* wt, const unsigned* amax_in, int Cin, int Cout, const float* in2, const float* wt2,
@@ -561,6 +743,7 @@ hipError_t launch_conv_h2_batch(const ConvBatch& b0, hipStream_t stream) {
         if (!h2_operands_ok(b.wt_h2, im.amax_in, b.Cin, b.Cout, im.in2, im.wt2_f32, im.amax_in2, im.amax_w2, b.Cin2))
             return hipErrorInvalidValue;
         if ((size_t)im.H * im.W * b.Cin * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
+        if ((b.unpool != 0) != (im.pcode_in != nullptr)) return hipErrorInvalidValue;
         blocks16 += (long)((im.H + 15) / 16) * ((im.W + 15) / 16) * (b.Cout / 128);
     }
     const int th = h2_tile_rows(b.Cout, blocks16), bn = wide ? 128 : 64;

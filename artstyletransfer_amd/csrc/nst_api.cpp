@@ -46,6 +46,9 @@ struct ActSet {                 // activations of one forward pass, NHWC
     // ids: act[l] -> l; the Gram factor S of style layer q -> NL + q; the gradient w.r.t. the pre-ReLU output of
     // layer l (or a bound of it: the pooled gradient it was un-pooled from) -> NL + 5 + l
     unsigned* amax = nullptr;
+    // arg-max codes of the four max-pools, written by the fused pooling of the f16x2 forward launches and read by
+    // the un-pooling loader of the input-gradient launch below each pool: [H/2*W/2][C/32][4] words
+    unsigned* pcode[4] = {};
     size_t bytes = 0;
 };
 constexpr int AMAX_IDS = 2 * NST_VGG19_CONVS + 5;
@@ -172,6 +175,8 @@ int alloc_acts(nst_ctx* ctx, ActSet& a, int h, int w) {
         const size_t n = (size_t)(a.h[l] / 2) * (a.w[l] / 2) * kCout[l];
         NSTCHK(dev_alloc_t(ctx, &a.pool[k], n));
         a.bytes += n * 4;
+        NSTCHK(dev_alloc_t(ctx, &a.pcode[k], n / 8));          // n / 32 channel groups x 4 words
+        a.bytes += n / 8 * 4;
     }
     size_t need = 0;
     for (int l = 1; l < NL; ++l) {
@@ -203,7 +208,7 @@ int alloc_acts(nst_ctx* ctx, ActSet& a, int h, int w) {
 }
 void free_acts(nst_ctx* ctx, ActSet& a) {
     for (int l = 0; l < NL; ++l) { dev_free(a.act[l]); a.act[l] = nullptr; }
-    for (int k = 0; k < 4; ++k) { dev_free(a.pool[k]); a.pool[k] = nullptr; }
+    for (int k = 0; k < 4; ++k) { dev_free(a.pool[k]); a.pool[k] = nullptr; dev_free(a.pcode[k]); a.pcode[k] = nullptr; }
     dev_free(a.splitk); a.splitk = nullptr; a.splitk_floats = 0;
     dev_free(a.amax); a.amax = nullptr;
     for (int l = 0; l < NL; ++l) { dev_free(a.bits[l]); a.bits[l] = nullptr; a.bits_valid[l] = false; }
@@ -527,6 +532,7 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
             im.out = a.act[l]; im.H = a.h[l]; im.W = a.w[l];
             im.bits_out = a.bits[l];
             im.pool_out = (pa >= 0) ? a.pool[pa] : nullptr;
+            im.pcode_out = (pa >= 0 && h2) ? a.pcode[pa] : nullptr;
             a.bits_valid[l] = a.bits[l] != nullptr;
             if (pa >= 0) a.pooled[pa] = true;
             im.amax_in = amax_act(a, l - 1); im.amax_out = amax_act(a, l);
@@ -575,6 +581,10 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wd_bf[l]; b.bias = nullptr; b.Cin = kCout[l]; b.Cout = kCin[l]; b.relu = 0;
         b.wt_h2 = ctx->wd_h2[l]; b.wt_h2_inv = ctx->wd_h2_inv[l];
+        // f16x2: when a max-pool follows layer l, cur[] holds the gradient w.r.t. the POOLED map and this launch's
+        // loader un-pools it through the arg-max code (no un-pool kernel, no full-size gradient round trip)
+        const int pl = pool_index_after(l);
+        b.unpool = (h2 && pl >= 0) ? 1 : 0;
         b.Cin2 = (pk < 0 && style_q >= 0) ? kCout[m] : 0;
         double flops = 0;
         for (int k = 0; k < n; ++k) {
@@ -582,6 +592,7 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
             ActSet& a = L.acts;
             ConvImage& im = b.img[k];
             im.in = cur[k]; im.out = oth[k]; im.H = a.h[l]; im.W = a.w[l];
+            im.pcode_in = b.unpool ? a.pcode[pl] : nullptr;
             im.amax_in = amax_grad(a, l); im.amax_out = amax_grad(a, l - 1);
             flops += conv_flops(im.H, im.W, b.Cin, b.Cout, 9);
             if (pk >= 0) continue;
@@ -603,7 +614,7 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
         }
         for (int k = 0; k < n; ++k) {
             ActSet& a = ctx->lv[lv[k]].acts;
-            if (pk >= 0) {
+            if (pk >= 0 && !h2) {
                 Timer t(ctx, s, K_OTHER, 0);
                 HIPCHK(ctx, launch_maxpool_bwd_relu(a.act[l - 1], oth[k], a.h[l - 1], a.w[l - 1], kCout[l - 1], cur[k], s));
             } else {

@@ -37,6 +37,12 @@ struct ConvParams {
     const unsigned* amax_in2;  // ... of `in2`
     const unsigned* amax_w2;   // ... of `wt2_f32`
     unsigned* amax_out;        // optional: absmax of `out` is recorded here (atomic max; zero it beforehand)
+    // un-pooling fused into the operand loader (input-gradient launches that follow a max-pool): `in` is then the
+    // gradient w.r.t. the POOLED map, [H/2][W/2][Cin], and pcode_in the arg-max code of that pool
+    // ([H/2*W/2][Cin/32][4 window positions] words, bit = channel & 31: set where that position held the window's
+    // first maximum and it was positive); pcode_out: a forward launch with pool_out writes that code
+    const unsigned* pcode_in;
+    unsigned* pcode_out;
 };
 
 constexpr int NST_AMAX_SLOTS = 64;
@@ -60,6 +66,8 @@ struct ConvImage {
     const unsigned* amax_in2;
     const unsigned* amax_w2;
     unsigned* amax_out;
+    const unsigned* pcode_in;
+    unsigned* pcode_out;
 };
 struct ConvBatch {
     ConvImage img[8];
@@ -69,6 +77,7 @@ struct ConvBatch {
     int Cin, Cout, Cin2, relu;
     const void* wt_h2;       // conv_h2 only
     float wt_h2_inv;
+    int unpool;              // every image's `in` is a pooled gradient to be un-pooled through pcode_in
 };
 
 // conv_mfma.hip

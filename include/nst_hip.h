@@ -159,9 +159,11 @@ int nst_noise_blend(nst_ctx* ctx, const float* content, const float* noise, int 
 /* dst = alpha * src (init_method 'random': 0.5 * noise, :351) */
 int nst_scale(nst_ctx* ctx, const float* src, float alpha, size_t n, float* dst, void* stream);
 
-/* arithmetic of the 3x3 convolutions: 1 = bf16 matrix pipe, both operands cut into three bf16 pieces that
- * sum to the fp32 value exactly, 6 MFMAs per product, fp32 accumulate (default; fp32-level error);
- * 0 = fp32 MFMA (v_mfma_f32_32x32x2_f32; environment NST_CONV=f32 at context creation). */
+/* arithmetic of the 3x3 convolutions (environment NST_CONV at context creation):
+ *   2 = "f16x2" (default): fp16 matrix pipe, both operands cut into two scaled fp16 pieces, 3 MFMAs per product
+ *       block, main and cross terms in separate fp32 accumulators (error measured against fp64 = an fp32 MFMA's);
+ *   1 = "bf16x3": bf16 matrix pipe, three bf16 pieces that sum to the fp32 value exactly, 6 MFMAs;
+ *   0 = "f32": fp32 MFMA (v_mfma_f32_32x32x2_f32). */
 int nst_conv_mode(const nst_ctx* ctx);
 
 /* workspace bytes currently held by the context (activations, gradients, history, targets) */
