@@ -11,6 +11,7 @@
 namespace nst {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
@@ -81,6 +82,32 @@ __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restric
     }
 
     float amax = 0.f;
+    if (y0 + F_TH <= H && x0 + F_TW <= W && (size_t)H * W * 256 < 0xFFFFFF00ull) {
+        // interior tile: buffer stores = per-lane byte offset + a scalar offset per element, no bounds tests
+        // (the same form as conv_h2.hip's fast epilogue)
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, (unsigned)((size_t)H * W * 256), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(bits_out, 0, bits_out ? (unsigned)((size_t)H * W * 8) : 0u, 0x00020000);
+        const int pix0 = (y0 + wave * 4) * W + x0 + 4 * half;
+        const unsigned vbase = (unsigned)(pix0 * 256 + l31 * 4);
+        const unsigned wlane = (l31 == 0) ? (unsigned)(pix0 * 8) : 0xFFFFFF00u;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float bv = bias[nt * 32 + l31];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int poff = ((r >> 3) + 2 * mt) * W + (r & 3) + 8 * ((r >> 2) & 1);      // pixel offset (scalar)
+                    const float v = fmaxf(acc[mt][nt][r] + bv, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, vbase, poff * 256 + nt * 128, 0);
+                    amax = fmaxf(amax, v);
+                    if (bits_out) {
+                        const unsigned long long bal = __ballot(v > 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(half ? (unsigned)(bal >> 32) : (unsigned)bal, rs_bits, wlane, poff * 8 + nt * 4, 0);
+                    }
+                }
+        }
+    } else {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int co = nt * 32 + l31;
@@ -103,6 +130,7 @@ __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restric
                     if (l31 == 0 && inb) bits_out[((size_t)y * W + xx) * 2 + nt] = half ? (unsigned)(bal >> 32) : (unsigned)bal;
                 }
             }
+    }
     }
     if (amax_out) {
         // absmax of the output for the fp16-piece convolution that consumes it (conv_h2.hip)
@@ -140,7 +168,10 @@ __global__ __launch_bounds__(256) void conv1_1_dgrad_kernel(const float* __restr
     const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
     const int y0 = ty * D_T, x0 = tx * D_T;
     const int py = tid >> 4, px = tid & 15;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    // channels 0 and 1 accumulate as a pair (v_pk_fma_f32 with the gradient value broadcast), channel 2 alone: two
+    // VALU instructions per (gradient value) instead of three on a VALU-bound kernel
+    f32x2 a01 = {0.f, 0.f};
+    float a2 = 0.f;
     for (int chunk = 0; chunk < 64 / D_KC; ++chunk) {
         if (chunk) __syncthreads();
         for (int u = tid; u < D_UNITS; u += 256) {
@@ -162,8 +193,7 @@ __global__ __launch_bounds__(256) void conv1_1_dgrad_kernel(const float* __restr
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const f32x4 w = wv[q * 4 + k];
-                    a0 += v[k] * w[0];
-                    a1 += v[k] * w[1];
+                    a01 += f32x2{v[k], v[k]} * f32x2{w[0], w[1]};
                     a2 += v[k] * w[2];
                 }
             }
@@ -172,8 +202,8 @@ __global__ __launch_bounds__(256) void conv1_1_dgrad_kernel(const float* __restr
     const int y = y0 + py, x = x0 + px;
     if (y < H && x < W) {
         const size_t HW = (size_t)H * W, i = (size_t)y * W + x;
-        gx[i] = a0;
-        gx[HW + i] = a1;
+        gx[i] = a01[0];
+        gx[HW + i] = a01[1];
         gx[2 * HW + i] = a2;
     }
 }
