@@ -434,9 +434,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     };
 
     // scales of the operand tensors (recorded absmax -> power of two) and of the frozen weights
-    float sa1, ia1;
-    tensor_scale(p.amax_in, lane, sa1, ia1);
-    const float inv = ia1 * p.wt_h2_inv;
+    // (Cin == 0: a launch of the second source alone, e.g. the Gram backward at the top of the chain, dF = F S)
+    const bool has_main = p.Cin > 0;
+    float sa1 = 1.f, ia1 = 1.f;
+    if (has_main) tensor_scale(p.amax_in, lane, sa1, ia1);
+    const float w1_inv = has_main ? p.wt_h2_inv : 1.f;
+    const float inv = ia1 * w1_inv;
     if (p.in2) {
         // The Gram backward rides on this launch with its own scales; it runs first and the accumulators are then
         // re-expressed in the scale of the main source (powers of two: exact).
@@ -444,7 +447,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         tensor_scale(p.amax_in2, lane, sa2, ia2);
         tensor_scale(p.amax_w2, lane, sw2, iw2);
         gram_source(p.in2, p.Cin2, p.wt2_f32, sa2, sw2);
-        const float ratio = (ia2 * sa1) * (iw2 * (1.f / p.wt_h2_inv));
+        const float ratio = (ia2 * sa1) * (iw2 * (1.f / w1_inv));
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -452,7 +455,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { accm[a][b][r] *= ratio; accx[a][b][r] *= ratio; }
     }
-    main_source(p.in, p.Cin, p.wt_h2, sa1);
+    if (has_main) main_source(p.in, p.Cin, p.wt_h2, sa1);
 
     // epilogue: D[m][n]: n = lane&31, m = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int words = p.Cout >> 5;          // ReLU bit-mask words per pixel
@@ -727,7 +730,8 @@ static void launch_single_cfg(const ConvParams& p, int blocks, hipStream_t strea
 
 static bool h2_operands_ok(const void* wt, const unsigned* amax_in, int Cin, int Cout, const float* in2, const float* wt2,
                            const unsigned* a2, const unsigned* w2, int Cin2) {
-    if (Cin % 32 != 0 || Cout % 64 != 0 || !wt || !amax_in) return false;
+    if (Cin % 32 != 0 || Cout % 64 != 0) return false;
+    if (Cin > 0 ? (!wt || !amax_in) : !in2) return false;       // Cin == 0: the second source alone
     if (in2 && (!wt2 || !a2 || !w2 || Cin2 % 32 != 0 || Cin2 != Cout)) return false;
     return true;
 }
@@ -742,7 +746,7 @@ hipError_t launch_conv_h2_batch(const ConvBatch& b0, hipStream_t stream) {
         const ConvImage& im = b.img[i];
         if (!h2_operands_ok(b.wt_h2, im.amax_in, b.Cin, b.Cout, im.in2, im.wt2_f32, im.amax_in2, im.amax_w2, b.Cin2))
             return hipErrorInvalidValue;
-        if ((size_t)im.H * im.W * b.Cin * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
+        if ((size_t)im.H * im.W * (b.Cin > b.Cin2 ? b.Cin : b.Cin2) * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
         if ((b.unpool != 0) != (im.pcode_in != nullptr)) return hipErrorInvalidValue;
         blocks16 += (long)((im.H + 15) / 16) * ((im.W + 15) / 16) * (b.Cout / 128);
     }
@@ -764,7 +768,7 @@ hipError_t launch_conv_h2(const ConvParams& p0, hipStream_t stream) {
     if (!h2_operands_ok(p0.wt_h2, p0.amax_in, p0.Cin, p0.Cout, p0.in2, p0.wt2_f32, p0.amax_in2, p0.amax_w2, p0.Cin2))
         return hipErrorInvalidValue;
     // 32-bit buffer offsets: the input tensor must stay below 4 GiB (callers fall back to conv_mfma.hip beyond)
-    if ((size_t)p0.H * p0.W * p0.Cin * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
+    if ((size_t)p0.H * p0.W * (p0.Cin > p0.Cin2 ? p0.Cin : p0.Cin2) * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
     ConvParams p = p0;
     p.ksplit = 1;
     const bool wide = (p.Cout % 128 == 0);

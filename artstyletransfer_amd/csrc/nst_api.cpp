@@ -189,8 +189,8 @@ int alloc_acts(nst_ctx* ctx, ActSet& a, int h, int w) {
         if (bwd > px * kCin[l] && bwd > need) need = bwd;
     }
     // layers m whose ReLU mask a non-pooling input-gradient launch consumes
-    const int mask_layers[8] = {0, 2, 4, 5, 6, 8, 9, 10};
-    for (int k = 0; k < 8; ++k) {
+    const int mask_layers[9] = {0, 2, 4, 5, 6, 8, 9, 10, 12};     // (12: the Gram backward at relu5_1)
+    for (int k = 0; k < 9; ++k) {
         const int m = mask_layers[k];
         const size_t nw = (size_t)a.h[m] * a.w[m] * (kCout[m] / 32);
         NSTCHK(dev_alloc_t(ctx, &a.bits[m], nw));
@@ -556,22 +556,35 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
     }
     // ---- backward
     float* cur[NST_MAX_LEVELS]; float* oth[NST_MAX_LEVELS];
-    for (int k = 0; k < n; ++k) {
+    for (int k = 0; k < n; ++k) { cur[k] = ctx->lv[lv[k]].gbuf[0]; oth[k] = ctx->lv[lv[k]].gbuf[1]; }
+    if (h2) {
+        // top of the chain: g(pre-ReLU of conv5_1) = mask(relu5_1 * S) - the second K source of the fp16 kernel on
+        // its own (no 3x3 part), one launch for all levels; its epilogue applies the ReLU mask and records the absmax
+        const int l = NL - 1;
+        ConvBatch b{};
+        b.n = n; b.Cin = 0; b.Cout = kCout[l]; b.Cin2 = kCout[l]; b.relu = 0; b.wt_h2_inv = 1.f;
+        double flops = 0;
+        for (int k = 0; k < n; ++k) {
+            LevelWs& L = ctx->lv[lv[k]];
+            ActSet& a = L.acts;
+            ConvImage& im = b.img[k];
+            im.out = cur[k]; im.H = a.h[l]; im.W = a.w[l];
+            im.in2 = a.act[l]; im.wt2_f32 = L.S[4]; im.amax_in2 = amax_act(a, l); im.amax_w2 = amax_S(a, 4);
+            im.bits_in = a.bits[l]; im.amax_out = amax_grad(a, l);
+            flops += conv_flops(im.H, im.W, b.Cin2, b.Cout, 1);
+        }
+        Timer t(ctx, s, K_GRAM, flops);
+        HIPCHK(ctx, launch_conv_h2_batch(b, s));
+    }
+    for (int k = 0; k < n && !h2; ++k) {
         LevelWs& L = ctx->lv[lv[k]];
         ActSet& a = L.acts;
-        cur[k] = L.gbuf[0]; oth[k] = L.gbuf[1];
         const int l = NL - 1;
         ConvParams p{};
         p.in = a.act[l]; p.wt = L.S[4]; p.out = cur[k]; p.mask = a.act[l];
         p.H = a.h[l]; p.W = a.w[l]; p.Cin = kCout[l]; p.Cout = kCout[l];
-        {
-            Timer t(ctx, s, K_GRAM, conv_flops(p.H, p.W, p.Cin, p.Cout, 1));
-            HIPCHK(ctx, launch_conv_mfma(p, 1, s));
-        }
-        if (h2) {
-            Timer t(ctx, s, K_OTHER, 0);
-            HIPCHK(ctx, launch_absmax_slots(cur[k], (size_t)p.H * p.W * p.Cout, amax_grad(a, l), s));
-        }
+        Timer t(ctx, s, K_GRAM, conv_flops(p.H, p.W, p.Cin, p.Cout, 1));
+        HIPCHK(ctx, launch_conv_mfma(p, 1, s));
     }
     for (int l = NL - 1; l >= 1; --l) {
         const int pk = pool_index_after(l - 1);

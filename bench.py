@@ -69,7 +69,9 @@ def mfma_roofline(mode, algorithmic_flops, ms, launches, extra=None):
            "what": "3x3 conv forward + input gradient (+ fused Gram backward)",
            "mfma_dtype": MFMA_DTYPE[mode],
            "achieved": hw, "peak": MFMA_PEAK[mode], "unit": "TFLOP/s", "frac": hw / MFMA_PEAK[mode],
-           "algorithmic_tflops": alg, "traffic": None, "launches": launches, "avg_launch_ms": ms / max(launches, 1),
+           "algorithmic_tflops": alg, "mfma_work_factor": MFMA_WORK_FACTOR[mode],
+           "frac_algorithmic_of_fp32_mfma_peak": alg / MFMA_PEAK["f32"],
+           "traffic": None, "launches": launches, "avg_launch_ms": ms / max(launches, 1),
            "flops_per_launch_avg": algorithmic_flops / max(launches, 1)}
     if extra:
         out.update(extra)
