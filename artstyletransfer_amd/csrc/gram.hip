@@ -175,17 +175,16 @@ struct GramH2Cfg {
 };
 
 template <int TS>
-__global__ __launch_bounds__(256, 2) void gram_h2_kernel(const float* __restrict__ f, size_t N, int C, int nsplit,
-                                                         size_t pix_per_split, const unsigned* __restrict__ amax,
-                                                         float* __restrict__ part) {
+__device__ __forceinline__ void gram_h2_body(const float* __restrict__ f, size_t N, int C, int nsplit, size_t pix_per_split,
+                                             const unsigned* __restrict__ amax, float* __restrict__ part, const int bid) {
     using G = GramH2Cfg<TS>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_h2[];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
 
-    const int split = blockIdx.x % nsplit;
-    int tp = blockIdx.x / nsplit;
+    const int split = bid % nsplit;
+    int tp = bid / nsplit;
     const int T = C / TS;
     int ti = 0;
     while (tp >= T - ti) { tp -= T - ti; ++ti; }
@@ -346,6 +345,23 @@ __global__ __launch_bounds__(256, 2) void gram_h2_kernel(const float* __restrict
     }
 }
 
+template <int TS>
+__global__ __launch_bounds__(256, 2) void gram_h2_kernel(const float* __restrict__ f, size_t N, int C, int nsplit,
+                                                         size_t pix_per_split, const unsigned* __restrict__ amax,
+                                                         float* __restrict__ part) {
+    gram_h2_body<TS>(f, N, C, nsplit, pix_per_split, amax, part, blockIdx.x);
+}
+// several maps (the style taps of every pyramid level of a closure) in one launch: their workgroups are numbered
+// item by item, so the short ones fill the tail of the long ones
+template <int TS>
+__global__ __launch_bounds__(256, 2) void gram_h2_batch_kernel(GramBatch b) {
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.it[i].part_end) ++i;
+    const GramItem& it = b.it[i];
+    gram_h2_body<TS>(it.f, it.N, it.C, it.nsplit, it.pix_per_split, it.amax, it.part,
+                     (int)blockIdx.x - (i ? b.it[i - 1].part_end : 0));
+}
+
 // generic fallback for channel counts that are not a multiple of 64 (unit-parity API only)
 __global__ void gram_generic_kernel(const float* __restrict__ f, size_t N, int C, float* __restrict__ part) {
     const int i = blockIdx.x / C, j = blockIdx.x % C;
@@ -392,6 +408,12 @@ hipError_t gram_init_device() {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_h2_kernel<128>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, GramH2Cfg<128>::LDS_BYTES);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_h2_batch_kernel<128>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, GramH2Cfg<128>::LDS_BYTES);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_h2_batch_kernel<64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, GramH2Cfg<64>::LDS_BYTES);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_h2_kernel<64>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, GramH2Cfg<64>::LDS_BYTES);
 }
@@ -430,25 +452,24 @@ hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, cons
 // G = (sum of the slabs, in slab order) / divisor; optional target: S = coef * (G - Gt) and the partial sums
 // of (G - Gt)^2.  A block owns 32 consecutive elements; its 8 lane groups each add every 8th slab, then the
 // 8 group sums are added in group order - a fixed order, so the result is reproducible.
-__global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ part, int nslabs, int C, int ts,
-                                                          float divisor, const float* __restrict__ target, float coef,
-                                                          float* __restrict__ gram_out, float* __restrict__ S,
-                                                          unsigned short* __restrict__ S_bf,
-                                                          unsigned* __restrict__ S_amax,
-                                                          double* __restrict__ mse_partial) {
+__device__ __forceinline__ void gram_finish_body(const float* __restrict__ part, int nslabs, int C, int ts, float divisor,
+                                                 const float* __restrict__ target, float coef, float* __restrict__ gram_out,
+                                                 float* __restrict__ S, unsigned short* __restrict__ S_bf,
+                                                 unsigned* __restrict__ S_amax, double* __restrict__ mse_partial,
+                                                 const unsigned bid) {
     __shared__ float sh[8][32];
     __shared__ double shd[32];
     const size_t CC = (size_t)C * C;
     const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const size_t e = (size_t)blockIdx.x * 32 + el;
+    const size_t e = (size_t)bid * 32 + el;
     const int i = (int)(e / C), j = (int)(e % C);
     // The tiled kernels compute the tiles on or above the diagonal only, and inside a diagonal tile the fp16-piece
     // kernel adds the two cross products of (i,j) and (j,i) in opposite orders: only elements with j >= i are read
     // (coalesced) and each result is written to (i,j) AND (j,i), which makes G exactly symmetric.  A 32-element
     // segment lies in one row (C % 32 == 0 for the tiled shapes); segments entirely below the diagonal do nothing.
     const bool tri = ts > 0;
-    if (tri && (int)((size_t)blockIdx.x * 32 % C) + 31 < (int)((size_t)blockIdx.x * 32 / C)) {
-        if (threadIdx.x == 0 && mse_partial) mse_partial[blockIdx.x] = 0.0;
+    if (tri && (int)((size_t)bid * 32 % C) + 31 < (int)((size_t)bid * 32 / C)) {
+        if (threadIdx.x == 0 && mse_partial) mse_partial[bid] = 0.0;
         return;
     }
     const bool mine = e < CC && (!tri || j >= i);
@@ -499,18 +520,73 @@ __global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restric
             // absmax of S for the fp16-piece convolution that multiplies by it (conv_h2.hip); lanes 0..31 here
 #pragma unroll
             for (int off = 16; off > 0; off >>= 1) sabs = fmaxf(sabs, __shfl_xor(sabs, off));
-            if (el == 0) atomicMax(S_amax + (blockIdx.x & (NST_AMAX_SLOTS - 1)), __float_as_uint(sabs));
+            if (el == 0) atomicMax(S_amax + (bid & (NST_AMAX_SLOTS - 1)), __float_as_uint(sabs));
         }
     }
     __syncthreads();
     if (threadIdx.x == 0 && mse_partial) {
         double t = 0.0;
         for (int k = 0; k < 32; ++k) t += shd[k];
-        mse_partial[blockIdx.x] = t;
+        mse_partial[bid] = t;
     }
+}
+__global__ __launch_bounds__(256) void gram_finish_kernel(const float* __restrict__ part, int nslabs, int C, int ts,
+                                                          float divisor, const float* __restrict__ target, float coef,
+                                                          float* __restrict__ gram_out, float* __restrict__ S,
+                                                          unsigned short* __restrict__ S_bf,
+                                                          unsigned* __restrict__ S_amax,
+                                                          double* __restrict__ mse_partial) {
+    gram_finish_body(part, nslabs, C, ts, divisor, target, coef, gram_out, S, S_bf, S_amax, mse_partial, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void gram_finish_batch_kernel(GramBatch b) {
+    int i = 0;
+    while (i + 1 < b.n && (int)blockIdx.x >= b.it[i].finish_end) ++i;
+    const GramItem& it = b.it[i];
+    gram_finish_body(it.part, it.nsplit, it.C, (it.C % 128 == 0) ? 128 : 64, it.divisor, it.target, it.coef, it.gram_out, it.S,
+                     it.S_bf, it.S_amax, it.mse_partial, blockIdx.x - (unsigned)(i ? b.it[i - 1].finish_end : 0));
 }
 
 int gram_finish_blocks(int C) { return (int)(((size_t)C * C + 31) / 32); }
+
+// Batched forms (fp16-piece kernels only: every item needs its absmax record, C = 64 or a multiple of 128, and its
+// own partial buffer of nsplit x C x C floats).  Fills nsplit / pix_per_split / the block prefixes.
+hipError_t launch_gram_batch(const GramBatch& b0, hipStream_t stream) {
+    if (b0.n < 1 || b0.n > NST_GRAM_BATCH_MAX) return hipErrorInvalidValue;
+    // partial products: one launch per tile shape
+    for (int ts = 128; ts >= 64; ts -= 64) {
+        GramBatch b{};
+        for (int i = 0; i < b0.n; ++i) {
+            const GramItem& src = b0.it[i];
+            if (gram_ts(src.C) != ts) continue;
+            if (!src.amax || src.N * (size_t)src.C * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
+            GramItem& it = b.it[b.n];
+            it = src;
+            const int kp = (ts == 128) ? 32 : 128;
+            const int T = it.C / ts, pairs = T * (T + 1) / 2;
+            const size_t chunks = (it.N + kp - 1) / kp;
+            it.nsplit = gram_nsplit(it.C, it.N);
+            it.pix_per_split = ((chunks + it.nsplit - 1) / it.nsplit) * kp;
+            it.part_end = (b.n ? b.it[b.n - 1].part_end : 0) + pairs * it.nsplit;
+            ++b.n;
+        }
+        if (b.n == 0) continue;
+        const int blocks = b.it[b.n - 1].part_end;
+        if (ts == 128) hipLaunchKernelGGL(gram_h2_batch_kernel<128>, dim3(blocks), dim3(256), GramH2Cfg<128>::LDS_BYTES, stream, b);
+        else hipLaunchKernelGGL(gram_h2_batch_kernel<64>, dim3(blocks), dim3(256), GramH2Cfg<64>::LDS_BYTES, stream, b);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    // ordered finish of all of them
+    GramBatch b = b0;
+    for (int i = 0; i < b.n; ++i) {
+        if (gram_ts(b.it[i].C) == 0) return hipErrorInvalidValue;
+        b.it[i].nsplit = gram_nsplit(b.it[i].C, b.it[i].N);          // = number of slabs
+        b.it[i].finish_end = (i ? b.it[i - 1].finish_end : 0) + gram_finish_blocks(b.it[i].C);
+        if (b.it[i].C % 32 != 0) b.it[i].S_bf = nullptr;
+    }
+    hipLaunchKernelGGL(gram_finish_batch_kernel, dim3(b.it[b.n - 1].finish_end), dim3(256), 0, stream, b);
+    return hipGetLastError();
+}
 
 hipError_t launch_gram_finish(const float* part, int nslabs, int C, float divisor, const float* target, float coef,
                               float* gram_out, float* S, unsigned short* S_bf, unsigned* S_amax, double* mse_partial,

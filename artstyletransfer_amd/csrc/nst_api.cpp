@@ -478,16 +478,18 @@ int gram_of(nst_ctx* ctx, const float* f_nhwc, size_t N, int C, const unsigned* 
     return NST_OK;
 }
 
-size_t gram_part_floats_for(int h, int w) {
-    size_t mx = 0;
-    for (int k = 0; k < 5; ++k) {
-        const int l = kStyleLayer[k];
+// partial-Gram workspace of one image: the five style layers one after the other (the batched launch works on
+// all of them at once); offset of layer k = gram_part_offset(h, w, k), total = gram_part_offset(h, w, 5)
+size_t gram_part_offset(int h, int w, int k) {
+    size_t off = 0;
+    for (int q = 0; q < k; ++q) {
+        const int l = kStyleLayer[q];
         const size_t N = (size_t)(h >> kScale[l]) * (w >> kScale[l]);
-        const size_t f = (size_t)gram_nsplit(kCout[l], N) * kCout[l] * kCout[l];
-        if (f > mx) mx = f;
+        off += (size_t)gram_nsplit(kCout[l], N) * kCout[l] * kCout[l];
     }
-    return mx;
+    return off;
 }
+size_t gram_part_floats_for(int h, int w) { return gram_part_offset(h, w, 5); }
 
 // ---- closure with every conv layer launched once for all pyramid levels ("batched") ----------------------
 // Layer l has the same weights and channel counts at every level, and layer l of any level depends only on
@@ -542,7 +544,33 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
         HIPCHK(ctx, h2 ? launch_conv_h2_batch(b, s) : launch_conv_bf3_batch(b, s));
     }
     // ---- style losses: Gram matrices, S = d loss / d G folded for the backward
-    for (int k = 0; k < n; ++k) {
+    if (h2) {
+        // every (level, style layer) pair in two partial launches (one per tile shape) and one finish launch
+        for (int k0 = 0; k0 < n; k0 += 3) {
+            GramBatch gb{};
+            double flops = 0;
+            for (int k = k0; k < n && k < k0 + 3; ++k) {
+                LevelWs& L = ctx->lv[lv[k]];
+                for (int q = 0; q < 5; ++q) {
+                    const int l = kStyleLayer[q];
+                    const int C = kCout[l];
+                    const size_t N = (size_t)L.acts.h[l] * L.acts.w[l];
+                    const double chw = (double)C * (double)N;
+                    GramItem& it = gb.it[gb.n++];
+                    it.f = L.acts.act[l]; it.N = N; it.C = C; it.amax = amax_act(L.acts, l);
+                    it.part = L.gram_part + gram_part_offset(L.h, L.w, q);
+                    it.divisor = (float)chw; it.target = L.gram_t[q];
+                    it.coef = (float)((double)sw * 4.0 / (5.0 * (double)C * C * chw));
+                    it.gram_out = nullptr; it.S = L.S[q]; it.S_bf = L.S_bf[q]; it.S_amax = amax_S(L.acts, q);
+                    it.mse_partial = L.style_partial[q];
+                    flops += 2.0 * (double)N * C * C;
+                }
+            }
+            Timer t(ctx, s, K_GRAM, flops);
+            HIPCHK(ctx, launch_gram_batch(gb, s));
+        }
+    }
+    for (int k = 0; k < n && !h2; ++k) {
         LevelWs& L = ctx->lv[lv[k]];
         for (int q = 0; q < 5; ++q) {
             const int l = kStyleLayer[q];
@@ -550,8 +578,8 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
             const size_t N = (size_t)L.acts.h[l] * L.acts.w[l];
             const double chw = (double)C * (double)N;
             const float coef = (float)((double)sw * 4.0 / (5.0 * (double)C * C * chw));
-            NSTCHK(gram_of(ctx, L.acts.act[l], N, C, h2 ? amax_act(L.acts, l) : nullptr, (float)chw, L.gram_part, L.gram_t[q], coef, nullptr, L.S[q],
-                           L.S_bf[q], h2 ? amax_S(L.acts, q) : nullptr, L.style_partial[q], s));
+            NSTCHK(gram_of(ctx, L.acts.act[l], N, C, nullptr, (float)chw, L.gram_part, L.gram_t[q], coef, nullptr, L.S[q],
+                           L.S_bf[q], nullptr, L.style_partial[q], s));
         }
     }
     // ---- backward

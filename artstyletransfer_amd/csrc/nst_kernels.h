@@ -177,6 +177,17 @@ hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, cons
 // S = coef * (G - Gt) (C x C, for the backward 1x1 conv).  gram_out / target / S / mse_partial nullable;
 // mse_partial: gram_finish_blocks(C) doubles.  `nslabs` = gram_nslabs(C, nsplit).
 int gram_nslabs(int C, int nsplit);
+// Several Gram matrices in two partial launches (one per tile shape) + one finish launch.  Per item the caller sets
+// f, N, C, amax, part (its own gram_nsplit(C, N) x C x C floats) and the finish arguments; the rest is filled in.
+constexpr int NST_GRAM_BATCH_MAX = 16;
+struct GramItem {
+    const float* f; size_t N; int C; const unsigned* amax; float* part;
+    float divisor; const float* target; float coef; float* gram_out; float* S; unsigned short* S_bf; unsigned* S_amax;
+    double* mse_partial;
+    int nsplit; size_t pix_per_split; int part_end, finish_end;     // filled by the launcher
+};
+struct GramBatch { GramItem it[NST_GRAM_BATCH_MAX]; int n; };
+hipError_t launch_gram_batch(const GramBatch& b, hipStream_t stream);
 int gram_finish_blocks(int C);
 // S_amax (nullable): NST_AMAX_SLOTS words receiving the absmax of S (atomic max; zero them beforehand).
 hipError_t launch_gram_finish(const float* part, int nslabs, int C, float divisor, const float* target, float coef,

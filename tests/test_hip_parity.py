@@ -314,6 +314,36 @@ def test_closure_execution_modes_agree(eng, vgg_weights, monkeypatch, env):
         other.close()
 
 
+@pytest.mark.parametrize("geo", [(63, 133, 1, 227, 293), (356, 151, 3, 356, 151), (103, 151, 3, 136, 329),
+                                 (89, 320, 2, 89, 320), (290, 32, 2, 290, 32), (336, 77, 3, 104, 271)])
+def test_f16x2_vs_exact_f32_mfma_random_geometries(vgg_weights, monkeypatch, geo):
+    """Odd sizes, foreign-size styles, 1-3 levels (geometries drawn by tools/fuzz_modes.py, which ran 40 of them):
+    the default closure (fp16-piece convolutions, batched levels, fused un-pooling, buffer-addressed epilogues on
+    interior tiles and the general form on edge tiles) against the same library's exact-f32-MFMA closure on the
+    per-level schedule.  An indexing bug shows as errors of order 1; arithmetic agrees to 1e-7 in the losses and
+    to the ReLU-flip noise in the gradient."""
+    from artstyletransfer_amd.engine import StyleEngine
+    h, w, nlev, hs, ws = geo
+    c, s = _levels(h, w, nlev, 1), _levels(hs, ws, nlev, 2)
+    x = dev(cpu_ref.prepare_img((0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(h, w, seed=9)).astype(np.float32)))
+    res = []
+    for env in ({"NST_CONV": "f32", "NST_BATCH": "0"}, {"NST_CONV": "f16x2", "NST_BATCH": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = StyleEngine(vgg_weights, 0)
+        try:
+            _setup(e, c, s)
+            g, l = e.closure(x, 1e3, 4e5, 1e2)
+            res.append((g.cpu().numpy(), l.cpu().numpy()))
+        finally:
+            e.close()
+    (g0, l0), (g1, l1) = res
+    np.testing.assert_allclose(l1[-1], l0[-1], rtol=1e-5)
+    np.testing.assert_allclose(l1[:-1].reshape(nlev, 4)[:, 0], l0[:-1].reshape(nlev, 4)[:, 0], rtol=2e-5)
+    assert np.isfinite(g1).all()
+    assert rel_l2(g1, g0) < GRAD_RTOL
+
+
 def test_closure_finite_difference(eng, vgg_weights):
     """Directional derivative of the HIP loss against its own gradient (size-independent property)."""
     c, s = _levels(64, 96, 2, 1), _levels(64, 96, 2, 2)
