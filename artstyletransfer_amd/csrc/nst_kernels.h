@@ -134,7 +134,7 @@ hipError_t launch_bicubic_down_bwd(const float* gy, int C, int h, int w, int oh,
                                    hipStream_t stream);
 
 // total variation: partial sums of |dx| and |dy| (NST_TV_BLOCKS x 2 doubles in `partial`)
-constexpr int TV_BLOCKS = 256;
+constexpr int TV_BLOCKS = 1024;
 hipError_t launch_tv_partial(const float* y, int C, int h, int w, double* partial, hipStream_t stream);
 // reduces the partials (fixed order), writes means to scal[0..1]; if grad: grad (+)= weight * d tv/dy
 hipError_t launch_tv_finish(const float* y, int C, int h, int w, const double* partial, float weight, float* grad,

@@ -256,11 +256,13 @@ __device__ __forceinline__ void cand_range(int i, float scale, int n_in, int n_o
 __global__ void bicubic_down_bwd_kernel(const float* __restrict__ gy, int C, int h, int w, int oh, int ow,
                                         float* __restrict__ gx, int accumulate) {
     const float sh = (float)h / (float)oh, sw = (float)w / (float)ow;
-    const size_t total = (size_t)C * h * w;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int ix = (int)(i % w);
-        const int iy = (int)((i / w) % h);
-        const int c = (int)(i / ((size_t)w * h));
+    // grid = (column blocks, C * h rows): no 64-bit division per element
+    const int ix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (ix >= w) return;
+    for (int row = blockIdx.y; row < C * h; row += gridDim.y) {
+        const int c = row / h;
+        const int iy = row - c * h;
+        const size_t i = (size_t)row * w + ix;
         int ylo, yhi, xlo, xhi;
         cand_range(iy, sh, h, oh, ylo, yhi);
         cand_range(ix, sw, w, ow, xlo, xhi);
@@ -282,10 +284,10 @@ __global__ void bicubic_down_bwd_kernel(const float* __restrict__ gy, int C, int
 
 hipError_t launch_bicubic_down_bwd(const float* gy, int C, int h, int w, int oh, int ow, float* gx, int accumulate,
                                    hipStream_t stream) {
-    const size_t total = (size_t)C * h * w;
-    if (total == 0) return hipSuccess;
-    hipLaunchKernelGGL(bicubic_down_bwd_kernel, dim3(cap_blocks(total, 256)), dim3(256), 0, stream, gy, C, h, w, oh, ow,
-                       gx, accumulate);
+    if ((size_t)C * h * w == 0) return hipSuccess;
+    const int rows = C * h;
+    hipLaunchKernelGGL(bicubic_down_bwd_kernel, dim3((w + 255) / 256, rows < 65535 ? rows : 65535), dim3(256), 0, stream, gy, C,
+                       h, w, oh, ow, gx, accumulate);
     return hipGetLastError();
 }
 
@@ -293,14 +295,17 @@ hipError_t launch_bicubic_down_bwd(const float* gy, int C, int h, int w, int oh,
 __global__ __launch_bounds__(256) void tv_partial_kernel(const float* __restrict__ y, int C, int h, int w,
                                                          double* __restrict__ partial) {
     __shared__ double sh[4];
-    const size_t total = (size_t)C * h * w;
+    // block b takes the image rows (c, r) with (c h + r) % TV_BLOCKS == b, a thread every 256th column: a fixed
+    // assignment (reproducible sums) without any per-element division
     float sx = 0.f, sy = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % w);
-        const int r = (int)((i / w) % h);
-        const float v = y[i];
-        if (x + 1 < w) sx += fabsf(v - y[i + 1]);
-        if (r + 1 < h) sy += fabsf(v - y[i + w]);
+    for (int row = blockIdx.x; row < C * h; row += gridDim.x) {
+        const int r = row % h;
+        const float* line = y + (size_t)row * w;
+        for (int x = threadIdx.x; x < w; x += blockDim.x) {
+            const float v = line[x];
+            if (x + 1 < w) sx += fabsf(v - line[x + 1]);
+            if (r + 1 < h) sy += fabsf(v - line[x + w]);
+        }
     }
     const double bx = block_reduce_sum((double)sx, sh);
     const double by = block_reduce_sum((double)sy, sh);
@@ -324,25 +329,27 @@ __global__ __launch_bounds__(256) void tv_finish_kernel(const float* __restrict_
     __shared__ double sh[4];
     __shared__ float m[2];
     // every block re-reduces the TV_BLOCKS partials in the same fixed order
-    const double px = (threadIdx.x < TV_BLOCKS) ? partial[2 * threadIdx.x] : 0.0;
-    const double py = (threadIdx.x < TV_BLOCKS) ? partial[2 * threadIdx.x + 1] : 0.0;
+    double px = 0.0, py = 0.0;
+    for (int b = threadIdx.x; b < TV_BLOCKS; b += blockDim.x) { px += partial[2 * b]; py += partial[2 * b + 1]; }
     const double tx = block_reduce_sum(px, sh);
     const double ty = block_reduce_sum(py, sh);
     const double nx = (double)C * h * (w - 1), ny = (double)C * (h - 1) * w;
     if (threadIdx.x == 0) {
         m[0] = (float)tx / (float)nx;
         m[1] = (float)ty / (float)ny;
-        if (blockIdx.x == 0 && means) { means[0] = m[0]; means[1] = m[1]; }
+        if (blockIdx.x == 0 && blockIdx.y == 0 && means) { means[0] = m[0]; means[1] = m[1]; }
     }
     __syncthreads();
     if (!grad) return;
     // d(mx^2 + my^2) = 2 mx d mx + 2 my d my ; d mx / d y[i] = (sign(y_i - y_{i+1}) - sign(y_{i-1} - y_i)) / nx
     const float cx = weight * 2.f * m[0] / (float)nx;
     const float cy = weight * 2.f * m[1] / (float)ny;
-    const size_t total = (size_t)C * h * w;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int x = (int)(i % w);
-        const int r = (int)((i / w) % h);
+    // grid = (column blocks, C * h rows)
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= w) return;
+    for (int row = blockIdx.y; row < C * h; row += gridDim.y) {
+        const int r = row % h;
+        const size_t i = (size_t)row * w + x;
         const float v = y[i];
         float gx = 0.f, gyv = 0.f;
         if (x + 1 < w) gx += sgn(v - y[i + 1]);
@@ -356,10 +363,9 @@ __global__ __launch_bounds__(256) void tv_finish_kernel(const float* __restrict_
 
 hipError_t launch_tv_finish(const float* y, int C, int h, int w, const double* partial, float weight, float* grad,
                             int accumulate, float* means, hipStream_t stream) {
-    const size_t total = (size_t)C * h * w;
-    const int blocks = grad ? cap_blocks(total, 256) : 1;
-    hipLaunchKernelGGL(tv_finish_kernel, dim3(blocks), dim3(256), 0, stream, y, C, h, w, partial, weight, grad,
-                       accumulate, means);
+    const int rows = C * h;
+    const dim3 grid = grad ? dim3((w + 255) / 256, rows < 65535 ? rows : 65535) : dim3(1, 1);
+    hipLaunchKernelGGL(tv_finish_kernel, grid, dim3(256), 0, stream, y, C, h, w, partial, weight, grad, accumulate, means);
     return hipGetLastError();
 }
 
