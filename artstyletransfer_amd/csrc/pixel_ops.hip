@@ -263,6 +263,34 @@ __global__ void bicubic_down_bwd_kernel(const float* __restrict__ gy, int C, int
         const int c = row / h;
         const int iy = row - c * h;
         const size_t i = (size_t)row * w + ix;
+        if (h == 2 * oh && w == 2 * ow && iy >= 2 && iy < h - 2 && ix >= 2 && ix < w - 2) {
+            // exact 1/2 (the pyramid's case), away from the clamped border: every output o reads 2o-1 .. 2o+2 with the
+            // weights of t = 0.5, so an input index receives from exactly two outputs per axis - even i = 2m: o = m-1
+            // (tap 3), o = m (tap 1); odd i = 2m+1: o = m (tap 2), o = m+1 (tap 0).  Same weights, same order and same
+            // expressions as the general form below: bit-identical, 4 loads instead of ~25 candidate evaluations.
+            const float A = -0.75f;
+            const float wo = cubic2(1.5f, A), wi = cubic1(0.5f, A);       // outer / inner tap weight
+            const int my = iy >> 1, mx = ix >> 1;
+            const int oy0 = (iy & 1) ? my : my - 1, ox0 = (ix & 1) ? mx : mx - 1;
+            const float wy0 = (iy & 1) ? wi : wo, wy1 = (iy & 1) ? wo : wi;
+            const float wx0 = (ix & 1) ? wi : wo, wx1 = (ix & 1) ? wo : wi;
+            const float* p0 = gy + (size_t)c * oh * ow + (size_t)oy0 * ow + ox0;
+            float acc = 0.f;
+            {
+                float r = 0.f;
+                r += wx0 * p0[0];
+                r += wx1 * p0[1];
+                acc += wy0 * r;
+            }
+            {
+                float r = 0.f;
+                r += wx0 * p0[ow];
+                r += wx1 * p0[ow + 1];
+                acc += wy1 * r;
+            }
+            gx[i] = accumulate ? gx[i] + acc : acc;
+            continue;
+        }
         int ylo, yhi, xlo, xhi;
         cand_range(iy, sh, h, oh, ylo, yhi);
         cand_range(ix, sw, w, ow, xlo, xhi);
@@ -364,7 +392,8 @@ __global__ __launch_bounds__(256) void tv_finish_kernel(const float* __restrict_
 hipError_t launch_tv_finish(const float* y, int C, int h, int w, const double* partial, float weight, float* grad,
                             int accumulate, float* means, hipStream_t stream) {
     const int rows = C * h;
-    const dim3 grid = grad ? dim3((w + 255) / 256, rows < 65535 ? rows : 65535) : dim3(1, 1);
+    // (every workgroup re-reduces the TV_BLOCKS partials first, so few workgroups that each walk many rows)
+    const dim3 grid = grad ? dim3((w + 255) / 256, rows < 96 ? rows : 96) : dim3(1, 1);
     hipLaunchKernelGGL(tv_finish_kernel, grid, dim3(256), 0, stream, y, C, h, w, partial, weight, grad, accumulate, means);
     return hipGetLastError();
 }
