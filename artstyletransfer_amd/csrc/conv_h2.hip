@@ -49,6 +49,7 @@ constexpr float LO_DOWN = 1.f / 2048.f;
 // Shapes in use:
 //   <16, 128, 2, 32>  512 threads, 16x16 pixels x 128 channels               the 128-channel-multiple layers
 //   < 8, 128, 1, 32>  512 threads,  8x16 pixels x 128 channels               their under-filled launches
+//   < 8, 128, 2, 16>  256 threads,  8x16 pixels x 128 channels, 61 KB LDS    128-channel layers with Cin <= 128
 //   <16,  64, 2, 16>  256 threads, 16x16 pixels x  64 channels, 70 KB LDS    the 64-channel layers: TWO workgroups
 //                     per CU, so that one's prologue / epilogue (a large share with K = 576) runs under the other's
 //                     MFMAs; 16-channel chunks keep the double-buffered patch of each within half the LDS
@@ -704,6 +705,8 @@ hipError_t conv_h2_init_device() {
     if (e == hipSuccess) e = init_one<16, 128, 2, 32, true>();
     if (e == hipSuccess) e = init_one<8, 128, 1, 32, true>();
     if (e == hipSuccess) e = init_one<16, 64, 2, 16, true>();
+    if (e == hipSuccess) e = init_one<8, 128, 2, 16, false>();
+    if (e == hipSuccess) e = init_one<8, 128, 2, 16, true>();
     return e;
 }
 
@@ -750,7 +753,8 @@ hipError_t launch_conv_h2_batch(const ConvBatch& b0, hipStream_t stream) {
         if ((b.unpool != 0) != (im.pcode_in != nullptr)) return hipErrorInvalidValue;
         blocks16 += (long)((im.H + 15) / 16) * ((im.W + 15) / 16) * (b.Cout / 128);
     }
-    const int th = h2_tile_rows(b.Cout, blocks16), bn = wide ? 128 : 64;
+    const bool shortk = wide && b.Cin > 0 && b.Cin <= NST_H2_SHORTK_CIN;      // 8-row tiles, two workgroups per CU
+    const int th = shortk ? 8 : h2_tile_rows(b.Cout, blocks16), bn = wide ? 128 : 64;
     int tiles = 0;
     for (int i = 0; i < b.n; ++i) {
         b.img[i].tiles_x = (b.img[i].W + 15) / 16;
@@ -759,6 +763,7 @@ hipError_t launch_conv_h2_batch(const ConvBatch& b0, hipStream_t stream) {
     }
     const int blocks = tiles * (b.Cout / bn);
     if (!wide) launch_batch_cfg<16, 64, 2, 16>(b, blocks, stream);
+    else if (shortk) launch_batch_cfg<8, 128, 2, 16>(b, blocks, stream);
     else if (th == 8) launch_batch_cfg<8, 128, 1, 32>(b, blocks, stream);
     else launch_batch_cfg<16, 128, 2, 32>(b, blocks, stream);
     return hipGetLastError();
@@ -773,11 +778,13 @@ hipError_t launch_conv_h2(const ConvParams& p0, hipStream_t stream) {
     p.ksplit = 1;
     const bool wide = (p.Cout % 128 == 0);
     const long blocks16 = (long)((p.H + 15) / 16) * ((p.W + 15) / 16) * (p.Cout / 128);
-    const int th = h2_tile_rows(p.Cout, blocks16), bn = wide ? 128 : 64;
+    const bool shortk = wide && p.Cin > 0 && p.Cin <= NST_H2_SHORTK_CIN;
+    const int th = shortk ? 8 : h2_tile_rows(p.Cout, blocks16), bn = wide ? 128 : 64;
     p.tiles_x = (p.W + 15) / 16;
     p.tiles_y = (p.H + th - 1) / th;
     const int blocks = p.tiles_x * p.tiles_y * (p.Cout / bn);
     if (!wide) launch_single_cfg<16, 64, 2, 16>(p, blocks, stream);
+    else if (shortk) launch_single_cfg<8, 128, 2, 16>(p, blocks, stream);
     else if (th == 8) launch_single_cfg<8, 128, 1, 32>(p, blocks, stream);
     else launch_single_cfg<16, 128, 2, 32>(p, blocks, stream);
     return hipGetLastError();

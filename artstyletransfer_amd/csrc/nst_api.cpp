@@ -246,9 +246,9 @@ void make_bf3(const float* w, int taps, int rows, int K, std::vector<uint16_t>& 
 // w: [taps][rows][K] fp32  ->  out: [taps][rows][K/kc][2][kc] fp16 pieces of w * s, s = the power of two that
 // brings the largest |w| into [2^14, 2^15); *inv = 1 / s (same cut as conv_h2.hip::cut2x4).  kc = channels per K
 // chunk of the kernel shape that consumes these weights: 32 when `rows` (its output channels) is a multiple of
-// 128, else 16 (conv_h2.hip, shapes in use).
+// 128 and K (its input channels) > NST_H2_SHORTK_CIN, else 16 (conv_h2.hip, shapes in use).
 void make_h2(const float* w, int taps, int rows, int K, std::vector<uint16_t>& out, float* inv) {
-    const int kc = (rows % 128 == 0) ? 32 : 16;
+    const int kc = (rows % 128 == 0 && K > NST_H2_SHORTK_CIN) ? 32 : 16;
     const size_t n = (size_t)taps * rows * K;
     float mx = 0.f;
     for (size_t i = 0; i < n; ++i) mx = std::max(mx, std::fabs(w[i]));

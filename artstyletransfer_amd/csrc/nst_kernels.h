@@ -46,6 +46,9 @@ struct ConvParams {
 };
 
 constexpr int NST_AMAX_SLOTS = 64;
+// conv_h2: launches with at most this many input channels (K <= 1152) use the 16-channel-chunk shapes, and the
+// host lays their pre-cut weights out in 16-channel chunks (make_h2)
+constexpr int NST_H2_SHORTK_CIN = 128;
 
 // One image (pyramid level) of a batched conv_bf3 launch; the layer's weights / channel counts are shared.
 struct ConvImage {
