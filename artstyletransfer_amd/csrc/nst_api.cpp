@@ -793,12 +793,16 @@ int nst_ctx_create(int device, const float* const* weights, const float* const* 
                 for (int c = 0; c < ci; ++c) tmp[((size_t)t * co + o) * ci + c] = W[((size_t)o * ci + c) * 9 + t];
         if (dev_alloc_t(ctx, &ctx->wf[l], n) != NST_OK) return bail(NST_E_NOMEM);
         if (hipMemcpy(ctx->wf[l], tmp.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
-        make_bf3(tmp.data(), 9, co, ci, tmp16);
-        if (dev_alloc(ctx, &ctx->wf_bf[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
-        if (hipMemcpy(ctx->wf_bf[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
-        make_h2(tmp.data(), 9, co, ci, tmp16, &ctx->wf_h2_inv[l]);
-        if (dev_alloc(ctx, &ctx->wf_h2[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
-        if (hipMemcpy(ctx->wf_h2[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+        // the 16-bit-piece copy of the active arithmetic only (a context is created per job: 0.2 s and 80 MB each)
+        if (ctx->conv_mode == 1) {
+            make_bf3(tmp.data(), 9, co, ci, tmp16);
+            if (dev_alloc(ctx, &ctx->wf_bf[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
+            if (hipMemcpy(ctx->wf_bf[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+        } else if (ctx->conv_mode == 2) {
+            make_h2(tmp.data(), 9, co, ci, tmp16, &ctx->wf_h2_inv[l]);
+            if (dev_alloc(ctx, &ctx->wf_h2[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
+            if (hipMemcpy(ctx->wf_h2[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+        }
         // input gradient: a conv with "Cout" = ci and "Cin" = co: wd[tap'][ci][co] = W[co][ci][2-ky'][2-kx']
         for (int t = 0; t < 9; ++t) {
             const int ky = 2 - t / 3, kx = 2 - t % 3;
@@ -807,12 +811,15 @@ int nst_ctx_create(int device, const float* const* weights, const float* const* 
         }
         if (dev_alloc_t(ctx, &ctx->wd[l], n) != NST_OK) return bail(NST_E_NOMEM);
         if (hipMemcpy(ctx->wd[l], tmp.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
-        make_bf3(tmp.data(), 9, ci, co, tmp16);
-        if (dev_alloc(ctx, &ctx->wd_bf[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
-        if (hipMemcpy(ctx->wd_bf[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
-        make_h2(tmp.data(), 9, ci, co, tmp16, &ctx->wd_h2_inv[l]);
-        if (dev_alloc(ctx, &ctx->wd_h2[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
-        if (hipMemcpy(ctx->wd_h2[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+        if (ctx->conv_mode == 1) {
+            make_bf3(tmp.data(), 9, ci, co, tmp16);
+            if (dev_alloc(ctx, &ctx->wd_bf[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
+            if (hipMemcpy(ctx->wd_bf[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+        } else if (ctx->conv_mode == 2) {
+            make_h2(tmp.data(), 9, ci, co, tmp16, &ctx->wd_h2_inv[l]);
+            if (dev_alloc(ctx, &ctx->wd_h2[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
+            if (hipMemcpy(ctx->wd_h2[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+        }
     }
     if (hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
