@@ -79,8 +79,17 @@ int oalloc(nst_opt* o, float** p, size_t n) {
     return NST_OK;
 }
 
-// one closure evaluation at x: decays lr, fills o->g, returns the total loss (host) - synchronises
-int eval_closure(nst_opt* o, const float* x, float cw, float sw, float tvw, hipStream_t s, float* loss_out) {
+// Scalars the host needs about the new gradient ride on the closure's own synchronisation (every separate read-back
+// is a stream sync that leaves the GPU idle until the host has enqueued the next launches).
+struct GradStats {
+    bool want_abs = false;            // max|g| and sum|g|  (lbfgs.py: opt_cond / first-step t)
+    const float* dot_with = nullptr;  // g . dot_with       (lbfgs.py: gtd_new of the line search)
+    float gmax = 0.f, gsum = 0.f, gdot = 0.f;
+};
+
+// one closure evaluation at x: decays lr, fills o->g, returns the total loss (host) - synchronises once
+int eval_closure(nst_opt* o, const float* x, float cw, float sw, float tvw, hipStream_t s, float* loss_out,
+                 GradStats* gs = nullptr) {
     o->lr *= 0.999;                                                          // neural_style_transfer.py:155-158
     OCHK(nst_closure_levels(o->ctx, x, cw, sw, tvw, o->level_mask, o->g, o->losses, s));
     if (o->hook) o->hook(o->hook_user);                                      // all-reduce(sum) over the ranks
@@ -88,7 +97,12 @@ int eval_closure(nst_opt* o, const float* x, float cw, float sw, float tvw, hipS
     const size_t off = o->loss_rows.size();
     o->loss_rows.resize(off + row);
     OHIP(o, hipMemcpyAsync(o->loss_rows.data() + off, o->losses, row * sizeof(float), hipMemcpyDeviceToHost, s));
+    float r[3] = {0.f, 0.f, 0.f};
+    if (gs && gs->want_abs) OHIP(o, launch_absmax_abssum(o->g, o->n, o->scratch, o->scal, s));
+    if (gs && gs->dot_with) OHIP(o, launch_dot(o->g, gs->dot_with, o->n, o->scratch, o->scal + 2, s));
+    if (gs) OHIP(o, hipMemcpyAsync(r, o->scal, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
     OHIP(o, hipStreamSynchronize(s));
+    if (gs) { gs->gmax = r[0]; gs->gsum = r[1]; gs->gdot = r[2]; }
     o->total_closures += 1;                                                  // :198
     *loss_out = o->loss_rows[off + row - 1];
     return NST_OK;
@@ -98,6 +112,27 @@ int dot(nst_opt* o, const float* a, const float* b, hipStream_t s, float* out) {
     OHIP(o, launch_dot(a, b, o->n, o->scratch, o->scal, s));
     OHIP(o, hipMemcpyAsync(out, o->scal, sizeof(float), hipMemcpyDeviceToHost, s));
     OHIP(o, hipStreamSynchronize(s));
+    return NST_OK;
+}
+// two dot products, one synchronisation
+int dot2(nst_opt* o, const float* a0, const float* b0, const float* a1, const float* b1, hipStream_t s, float* out0,
+         float* out1) {
+    float r[2];
+    OHIP(o, launch_dot(a0, b0, o->n, o->scratch, o->scal, s));
+    OHIP(o, launch_dot(a1, b1, o->n, o->scratch, o->scal + 1, s));
+    OHIP(o, hipMemcpyAsync(r, o->scal, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
+    OHIP(o, hipStreamSynchronize(s));
+    *out0 = r[0]; *out1 = r[1];
+    return NST_OK;
+}
+// g . d together with max|d|, sum|d|, one synchronisation
+int dot_and_absstats(nst_opt* o, const float* g, const float* d, hipStream_t s, float* gtd, float* mx, float* sum) {
+    float r[3];
+    OHIP(o, launch_absmax_abssum(d, o->n, o->scratch, o->scal, s));
+    OHIP(o, launch_dot(g, d, o->n, o->scratch, o->scal + 2, s));
+    OHIP(o, hipMemcpyAsync(r, o->scal, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    OHIP(o, hipStreamSynchronize(s));
+    *mx = r[0]; *sum = r[1]; *gtd = r[2];
     return NST_OK;
 }
 int absstats(nst_opt* o, const float* a, hipStream_t s, float* mx, float* sum) {
@@ -130,16 +165,16 @@ struct LsResult { double t; float f; int evals; };
 
 // torch:optim/lbfgs.py:40-209.  Gradients of bracket points are never needed by the caller with
 // max_iter == 1 (only f, g.d and t are consumed), so no gradient clones are kept.
-int strong_wolfe(nst_opt* o, float* x, double t, float f, float gtd, int max_ls, float cw, float sw, float tvw,
-                 hipStream_t s, LsResult* res) {
+int strong_wolfe(nst_opt* o, float* x, double t, float f, float gtd, float d_norm, int max_ls, float cw, float sw,
+                 float tvw, hipStream_t s, LsResult* res) {
     const double c1 = 1e-4, c2 = 0.9, tol_change = 1e-9;
-    float d_norm, dsum;
-    OCHK(absstats(o, o->d, s, &d_norm, &dsum));
     auto eval_at = [&](double tt, float* f_new, float* gtd_new) -> int {
         // x = x_init + t*d ; closure ; (x restored by the caller at the end)
         OHIP(o, launch_add_scaled(o->xinit, (float)tt, o->d, x, o->n, s));
-        OCHK(eval_closure(o, x, cw, sw, tvw, s, f_new));
-        OCHK(dot(o, o->g, o->d, s, gtd_new));
+        GradStats gs;
+        gs.dot_with = o->d;
+        OCHK(eval_closure(o, x, cw, sw, tvw, s, f_new, &gs));
+        *gtd_new = gs.gdot;
         return NST_OK;
     };
     float f_new, gtd_new;
@@ -215,10 +250,11 @@ int strong_wolfe(nst_opt* o, float* x, double t, float f, float gtd, int max_ls,
 int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t s, nst_step_info* info) {
     const double lr = o->lr;                                     // read before the closure decays it (lbfgs.py:349)
     float loss;
-    OCHK(eval_closure(o, x, cw, sw, tvw, s, &loss));
+    GradStats g0;
+    g0.want_abs = true;
+    OCHK(eval_closure(o, x, cw, sw, tvw, s, &loss, &g0));
     info->loss = loss;
-    float gmax, gsum;
-    OCHK(absstats(o, o->g, s, &gmax, &gsum));
+    const float gmax = g0.gmax, gsum = g0.gsum;
     if (gmax <= 1e-7f) { info->accepted = 0; info->t = 0.f; return NST_OK; }
     o->n_iter += 1;
     if (o->n_iter == 1) {
@@ -237,16 +273,14 @@ int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t 
         OCHK(take(&y)); OCHK(take(&st));
         OHIP(o, launch_sub(o->g, o->prev_g, y, o->n, s));
         OHIP(o, launch_scale_copy((float)o->t, o->d, st, o->n, s));
-        float ys;
-        OCHK(dot(o, y, st, s, &ys));
+        float ys, yy;
+        OCHK(dot2(o, y, st, y, y, s, &ys, &yy));
         if (ys > 1e-10f) {
             if ((int)o->old_dirs.size() == o->history) {
                 o->spare.push_back(o->old_dirs.front()); o->spare.push_back(o->old_stps.front());
                 o->old_dirs.erase(o->old_dirs.begin()); o->old_stps.erase(o->old_stps.begin()); o->ro.erase(o->ro.begin());
             }
             o->old_dirs.push_back(y); o->old_stps.push_back(st); o->ro.push_back(1.0f / ys);
-            float yy;
-            OCHK(dot(o, y, y, s, &yy));
             o->H_diag = ys / yy; o->H_is_one = false;
         } else {
             o->spare.push_back(y); o->spare.push_back(st);
@@ -277,13 +311,13 @@ int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t 
     } else {
         t = lr;
     }
-    float gtd;
-    OCHK(dot(o, o->g, o->d, s, &gtd));
+    float gtd, d_norm, d_sum;
+    OCHK(dot_and_absstats(o, o->g, o->d, s, &gtd, &d_norm, &d_sum));
     info->accepted = 0; info->t = 0.f;
     if (!(gtd > -1e-9f)) {
         OHIP(o, launch_copy(x, o->xinit, o->n, s));
         LsResult r;
-        OCHK(strong_wolfe(o, x, t, loss, gtd, o->max_eval - 1, cw, sw, tvw, s, &r));
+        OCHK(strong_wolfe(o, x, t, loss, gtd, d_norm, o->max_eval - 1, cw, sw, tvw, s, &r));
         t = r.t;
         if (t != 0.0) OHIP(o, launch_add_scaled(o->xinit, (float)t, o->d, x, o->n, s));
         else OHIP(o, launch_copy(o->xinit, x, o->n, s));
