@@ -60,6 +60,10 @@ SYMBOLS = {
                                                C.c_double, c_void]),
     "nst_noise_blend": (C.c_int, [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_double, c_void, c_void]),
     "nst_scale": (C.c_int, [c_void, c_void, C.c_float, C.c_size_t, c_void, c_void]),
+    "nst_window_sums_count": (C.c_int, [C.POINTER(C.c_size_t)]),
+    "nst_window_begin": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void]),
+    "nst_window_end": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, c_void, c_void,
+                                 c_void, c_void]),
     "nst_conv_mode": (C.c_int, [c_void]),
     "nst_ctx_bytes": (C.c_int, [c_void, C.POINTER(C.c_size_t)]),
     "nst_set_timing": (C.c_int, [c_void, C.c_int]),

@@ -286,7 +286,13 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             const_cast<float*>(wts), 0, (unsigned)((size_t)p.Cout * cin * 4), 0x00020000);
         unsigned a_voff[C::A_PER_T], b_voff[C::B_PER_T];
 #pragma unroll
-        for (int i = 0; i < C::A_PER_T; ++i) a_voff[i] = a_voff_of(i, tid, cin, false);
+        for (int i = 0; i < C::A_PER_T; ++i) {
+            a_voff[i] = a_voff_of(i, tid, cin, false);
+            // row window of the second source (a job evaluated on a stripe of a larger image adds the Gram backward on
+            // the rows it owns only): rows outside read as zeros
+            const int gy = y0 - 1 + ((tid + i * C::NT) / QP) / C::PW;
+            if (p.in2_rows > 0 && (unsigned)(gy - p.in2_row0) >= (unsigned)p.in2_rows) a_voff[i] = 0xFFFFFF00u;
+        }
 #pragma unroll
         for (int i = 0; i < C::B_PER_T; ++i) {
             const int u = tid + i * C::NT;
@@ -685,6 +691,7 @@ __global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_batch
     p.wt_h2 = b.wt_h2; p.wt_h2_inv = b.wt_h2_inv; p.wt2_f32 = im.wt2_f32;
     p.amax_in = im.amax_in; p.amax_in2 = im.amax_in2; p.amax_w2 = im.amax_w2; p.amax_out = im.amax_out;
     p.pcode_in = im.pcode_in; p.pcode_out = im.pcode_out;
+    p.in2_row0 = im.in2_row0; p.in2_rows = im.in2_rows;
     conv_h2_body<TH, BN, NTW, KC, UNPOOL>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), blockIdx.x % n_ct, blockIdx.x);
 }
 

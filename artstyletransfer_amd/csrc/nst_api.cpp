@@ -496,16 +496,22 @@ size_t gram_part_floats_for(int h, int w) { return gram_part_offset(h, w, 5); }
 // layer l-1 of that level, so the 12 forward and 12 input-gradient convolutions each become ONE launch whose
 // grid lists the tiles of level 0, then level 1, ...: the small levels fill the tail of the big level's grid
 // instead of running as under-filled launches.  Everything is ordered on the caller's stream.
-int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsigned level_mask, float cw, float sw,
-                    float tvw, hipStream_t s) {
-    int lv[NST_MAX_LEVELS], n = 0;
-    for (int i = 0; i < ctx->levels; ++i) {
-        if ((level_mask >> i) & 1u) lv[n++] = i;
-        else HIPCHK(ctx, hipMemsetAsync(gi[i], 0, (size_t)3 * ctx->lv[i].h * ctx->lv[i].w * sizeof(float), s));
-    }
-    if (n == 0) return NST_OK;
+// A job evaluated on a horizontal stripe of a larger image (spatial sharding): the level-0 image of this
+// context is rows [.., ..) of an H0-row image; the loss terms of its rows [row0, row0 + rows) are this context's,
+// with the normalisers of the full image.  Per-layer quantities scale by the layer's stride (row0, rows: multiples
+// of 16).  Style / content / TV sums of the owned rows go to `sums` (begin); after the caller has added the other
+// stripes' sums the backward uses them (end).
+struct Window {
+    int row0, rows, H0;
+    float* sums;          // begin: out;  end: in (summed over the stripes)
+};
+constexpr size_t kWinGramOff[5] = {0, 64 * 64, 64 * 64 + 128 * 128, 64 * 64 + 128 * 128 + 256 * 256,
+                                   64 * 64 + 128 * 128 + 256 * 256 + 512 * 512};
+constexpr size_t kWinScalarOff = 64 * 64 + 128 * 128 + 256 * 256 + 2 * 512 * 512;    // content SSE, TV x, TV y
+constexpr size_t kWinSums = kWinScalarOff + 4;
+
+int batched_forward(nst_ctx* ctx, const float* const* xi, const int* lv, int n, hipStream_t s, const Window* win) {
     const bool h2 = ctx->conv_mode == 2;
-    // ---- forward
     for (int k = 0; k < n; ++k) {
         LevelWs& L = ctx->lv[lv[k]];
         ActSet& a = L.acts;
@@ -514,7 +520,7 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
         if (h2) HIPCHK(ctx, hipMemsetAsync(a.amax, 0, (size_t)AMAX_IDS * NST_AMAX_SLOTS * 4, s));
         {
             Timer t(ctx, s, K_OTHER, 0);
-            HIPCHK(ctx, launch_tv_partial(xi[lv[k]], 3, L.h, L.w, L.tv_partial, s));
+            HIPCHK(ctx, launch_tv_partial(xi[lv[k]], 3, L.h, L.w, L.tv_partial, s, win ? win->row0 : 0, win ? win->rows : 0));
         }
         Timer t(ctx, s, K_CONV1, conv_flops(L.h, L.w, 3, 64, 9));
         HIPCHK(ctx, launch_conv1_1_fwd(xi[lv[k]], L.h, L.w, ctx->w11k, ctx->bias[0], a.act[0], a.bits[0],
@@ -543,7 +549,12 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
         Timer t(ctx, s, K_CONV3, flops, b.img[0].H, b.img[0].W, b.Cin, b.Cout, 9, l);
         HIPCHK(ctx, h2 ? launch_conv_h2_batch(b, s) : launch_conv_bf3_batch(b, s));
     }
-    // ---- style losses: Gram matrices, S = d loss / d G folded for the backward
+    return NST_OK;
+}
+
+// ---- style losses: Gram matrices, S = d loss / d G folded for the backward
+int batched_gram(nst_ctx* ctx, const int* lv, int n, float sw, hipStream_t s) {
+    const bool h2 = ctx->conv_mode == 2;
     if (h2) {
         // every (level, style layer) pair in two partial launches (one per tile shape) and one finish launch
         for (int k0 = 0; k0 < n; k0 += 3) {
@@ -582,7 +593,12 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
                            L.S_bf[q], nullptr, L.style_partial[q], s));
         }
     }
-    // ---- backward
+    return NST_OK;
+}
+
+int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, const int* lv, int n, float cw, float tvw,
+                     hipStream_t s, const Window* win, const float* win_means, double win_nx, double win_ny) {
+    const bool h2 = ctx->conv_mode == 2;
     float* cur[NST_MAX_LEVELS]; float* oth[NST_MAX_LEVELS];
     for (int k = 0; k < n; ++k) { cur[k] = ctx->lv[lv[k]].gbuf[0]; oth[k] = ctx->lv[lv[k]].gbuf[1]; }
     if (h2) {
@@ -599,6 +615,7 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
             im.out = cur[k]; im.H = a.h[l]; im.W = a.w[l];
             im.in2 = a.act[l]; im.wt2_f32 = L.S[4]; im.amax_in2 = amax_act(a, l); im.amax_w2 = amax_S(a, 4);
             im.bits_in = a.bits[l]; im.amax_out = amax_grad(a, l);
+            if (win) { im.in2_row0 = win->row0 >> kScale[l]; im.in2_rows = win->rows >> kScale[l]; }
             flops += conv_flops(im.H, im.W, b.Cin2, b.Cout, 1);
         }
         Timer t(ctx, s, K_GRAM, flops);
@@ -640,11 +657,22 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
             if (style_q >= 0) {
                 im.in2 = a.act[m]; im.wt2_bf = L.S_bf[style_q];
                 im.wt2_f32 = L.S[style_q]; im.amax_in2 = amax_act(a, m); im.amax_w2 = amax_S(a, style_q);
+                if (win) { im.in2_row0 = win->row0 >> kScale[m]; im.in2_rows = win->rows >> kScale[m]; }
                 flops += conv_flops(a.h[m], a.w[m], kCout[m], kCout[m], 1);
             } else if (m == kContentLayer) {
                 Timer t(ctx, s, K_OTHER, 0);
-                HIPCHK(ctx, launch_mse_grad(a.act[m], L.content_t, L.content_n,
-                                            (float)((double)cw * 2.0 / (double)L.content_n), oth[k], L.content_partial, s));
+                if (win) {
+                    // content gradient on the owned rows only (zero elsewhere), normalised by the full image's size
+                    const size_t off = (size_t)(win->row0 >> kScale[m]) * a.w[m] * kCout[m];
+                    const size_t cnt = (size_t)(win->rows >> kScale[m]) * a.w[m] * kCout[m];
+                    const double n_all = (double)(win->H0 >> kScale[m]) * a.w[m] * kCout[m];
+                    HIPCHK(ctx, hipMemsetAsync(oth[k], 0, L.content_n * sizeof(float), s));
+                    HIPCHK(ctx, launch_mse_grad(a.act[m] + off, L.content_t + off, cnt, (float)((double)cw * 2.0 / n_all),
+                                                oth[k] + off, L.content_partial, s));
+                } else {
+                    HIPCHK(ctx, launch_mse_grad(a.act[m], L.content_t, L.content_n,
+                                                (float)((double)cw * 2.0 / (double)L.content_n), oth[k], L.content_partial, s));
+                }
                 im.addend = oth[k];
             }
             im.bits_in = a.bits[m];
@@ -670,9 +698,26 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
             HIPCHK(ctx, launch_conv1_1_dgrad(cur[k], L.h, L.w, ctx->w11d, gi[lv[k]], s));
         }
         Timer t(ctx, s, K_OTHER, 0);
-        HIPCHK(ctx, launch_tv_finish(xi[lv[k]], 3, L.h, L.w, L.tv_partial, tvw, gi[lv[k]], 1, L.tv_means, s));
+        if (win)
+            HIPCHK(ctx, launch_tv_finish(xi[lv[k]], 3, L.h, L.w, L.tv_partial, tvw, gi[lv[k]], 1, nullptr, s, win->row0, win->rows,
+                                         win_means, win_nx, win_ny));
+        else
+            HIPCHK(ctx, launch_tv_finish(xi[lv[k]], 3, L.h, L.w, L.tv_partial, tvw, gi[lv[k]], 1, L.tv_means, s));
     }
     return NST_OK;
+}
+
+int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsigned level_mask, float cw, float sw,
+                    float tvw, hipStream_t s) {
+    int lv[NST_MAX_LEVELS], n = 0;
+    for (int i = 0; i < ctx->levels; ++i) {
+        if ((level_mask >> i) & 1u) lv[n++] = i;
+        else HIPCHK(ctx, hipMemsetAsync(gi[i], 0, (size_t)3 * ctx->lv[i].h * ctx->lv[i].w * sizeof(float), s));
+    }
+    if (n == 0) return NST_OK;
+    NSTCHK(batched_forward(ctx, xi, lv, n, s, nullptr));
+    NSTCHK(batched_gram(ctx, lv, n, sw, s));
+    return batched_backward(ctx, xi, gi, lv, n, cw, tvw, s, nullptr, nullptr, 0, 0);
 }
 
 void free_level(nst_ctx* ctx, LevelWs& L) {
@@ -1076,6 +1121,96 @@ static int closure_record(nst_ctx* ctx, const float* x, float cw, float sw, floa
         la.lv[i].owned = (int)((level_mask >> i) & 1u);
     }
     HIPCHK(ctx, launch_loss_assemble(la, main));
+    return NST_OK;
+}
+
+// ---- stripe (window) closure: spatial sharding of one pyramid level -------------------------------------
+int nst_window_sums_count(size_t* count) {
+    if (!count) return fail(nullptr, NST_E_ARG, "null argument");
+    *count = kWinSums;
+    return NST_OK;
+}
+
+static int window_check(nst_ctx* ctx, const float* xs, int row0, int rows, int H0) {
+    if (ctx->levels != 1) return fail(ctx, NST_E_STATE, "a stripe context is configured with levels_num = 1");
+    if (ctx->conv_mode != 2) return fail(ctx, NST_E_STATE, "the stripe closure runs on the f16x2 convolutions (NST_CONV unset)");
+    LevelWs& L = ctx->lv[0];
+    if (!L.targets) return fail(ctx, NST_E_STATE, "targets of the stripe not set");
+    if (!xs) return fail(ctx, NST_E_ARG, "null buffer");
+    if (row0 < 0 || rows < 16 || row0 % 16 || rows % 16 || row0 + rows > L.h || H0 < L.h || H0 % 16 || L.h % 16 || L.w % 16)
+        return fail(ctx, NST_E_ARG, "stripe rows must be multiples of 16 inside the stripe image, image sizes multiples of 16");
+    if ((size_t)L.h * L.w * 64 * 4 >= 0xFFFFFF00ull) return fail(ctx, NST_E_ARG, "stripe image too large for the f16x2 kernels");
+    return NST_OK;
+}
+
+int nst_window_begin(nst_ctx* ctx, const float* xs, int row0, int rows, int H0, float* sums, void* stream) {
+    NSTCHK(bind(ctx));
+    NSTCHK(window_check(ctx, xs, row0, rows, H0));
+    if (!sums) return fail(ctx, NST_E_ARG, "null buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LevelWs& L = ctx->lv[0];
+    ActSet& a = L.acts;
+    Window win{row0, rows, H0, sums};
+    const int lv[1] = {0};
+    const float* xi[1] = {xs};
+    NSTCHK(batched_forward(ctx, xi, lv, 1, s, &win));
+    // un-normalised Gram sums of the owned rows
+    for (int q = 0; q < 5; ++q) {
+        const int l = kStyleLayer[q], C = kCout[l];
+        const size_t off = (size_t)(row0 >> kScale[l]) * a.w[l] * C;
+        const size_t N = (size_t)(rows >> kScale[l]) * a.w[l];
+        const int ns = gram_nsplit(C, N);
+        HIPCHK(ctx, launch_gram_partial(a.act[l] + off, N, C, ns, amax_act(a, l), L.gram_part, s));
+        HIPCHK(ctx, launch_gram_finish(L.gram_part, gram_nslabs(C, ns), C, 1.f, nullptr, 0.f, sums + kWinGramOff[q], nullptr, nullptr,
+                                       nullptr, nullptr, s));
+    }
+    // content: sum of squared differences over the owned rows
+    {
+        const int m = kContentLayer;
+        const size_t off = (size_t)(row0 >> kScale[m]) * a.w[m] * kCout[m];
+        const size_t cnt = (size_t)(rows >> kScale[m]) * a.w[m] * kCout[m];
+        HIPCHK(ctx, launch_mse_grad(a.act[m] + off, L.content_t + off, cnt, 0.f, nullptr, L.content_partial, s));
+        HIPCHK(ctx, launch_sum_doubles(L.content_partial, MSE_BLOCKS, 1, 0, sums + kWinScalarOff, s));
+    }
+    // total variation: sums of |dx|, |dy| over the owned rows (batched_forward ran the windowed partial pass)
+    HIPCHK(ctx, launch_sum_doubles(L.tv_partial, TV_BLOCKS, 2, 0, sums + kWinScalarOff + 1, s));
+    HIPCHK(ctx, launch_sum_doubles(L.tv_partial, TV_BLOCKS, 2, 1, sums + kWinScalarOff + 2, s));
+    return NST_OK;
+}
+
+int nst_window_end(nst_ctx* ctx, const float* xs, int row0, int rows, int H0, float cw, float sw, float tvw, float* sums,
+                   float* gxs, float* losses, void* stream) {
+    NSTCHK(bind(ctx));
+    NSTCHK(window_check(ctx, xs, row0, rows, H0));
+    if (!sums || !gxs || !losses) return fail(ctx, NST_E_ARG, "null buffer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    LevelWs& L = ctx->lv[0];
+    ActSet& a = L.acts;
+    Window win{row0, rows, H0, sums};
+    // S = d loss / d G from the Gram sums of ALL stripes, normalised by the full image
+    for (int q = 0; q < 5; ++q) {
+        const int l = kStyleLayer[q], C = kCout[l];
+        const double chw = (double)C * (double)(H0 >> kScale[l]) * a.w[l];
+        const float coef = (float)((double)sw * 4.0 / (5.0 * (double)C * C * chw));
+        HIPCHK(ctx, launch_gram_finish(sums + kWinGramOff[q], 1, C, (float)chw, L.gram_t[q], coef, nullptr, L.S[q], L.S_bf[q],
+                                       amax_S(a, q), L.style_partial[q], s));
+    }
+    const double nx = 3.0 * H0 * (L.w - 1), ny = 3.0 * (H0 - 1) * L.w;
+    HIPCHK(ctx, launch_window_scalars(sums + kWinScalarOff, nx, ny, L.tv_means, L.content_partial, 0, s));   // means only
+    const int lv[1] = {0};
+    const float* xi[1] = {xs};
+    float* gi[1] = {gxs};
+    NSTCHK(batched_backward(ctx, xi, gi, lv, 1, cw, tvw, s, &win, L.tv_means, nx, ny));
+    // the level's loss row from the global sums (the backward's content pass left this stripe's partials behind)
+    HIPCHK(ctx, launch_window_scalars(sums + kWinScalarOff, nx, ny, L.tv_means, L.content_partial, MSE_BLOCKS, s));
+    LossAssembly la{};
+    la.levels = 1; la.cw = cw; la.sw = sw; la.tvw = tvw; la.out = losses;
+    la.lv[0].content_partial = L.content_partial;
+    la.lv[0].content_n = (size_t)(H0 >> kScale[kContentLayer]) * a.w[kContentLayer] * kCout[kContentLayer];
+    for (int k = 0; k < 5; ++k) { la.lv[0].style_partial[k] = L.style_partial[k]; la.lv[0].style_c[k] = kCout[kStyleLayer[k]]; }
+    la.lv[0].tv_means = L.tv_means;
+    la.lv[0].owned = 1;
+    HIPCHK(ctx, launch_loss_assemble(la, s));
     return NST_OK;
 }
 

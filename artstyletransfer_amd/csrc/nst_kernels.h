@@ -43,6 +43,7 @@ struct ConvParams {
     // first maximum and it was positive); pcode_out: a forward launch with pool_out writes that code
     const unsigned* pcode_in;
     unsigned* pcode_out;
+    int in2_row0, in2_rows;    // in2_rows > 0: the second source contributes on output rows [in2_row0, in2_row0 + in2_rows) only
 };
 
 constexpr int NST_AMAX_SLOTS = 64;
@@ -71,6 +72,7 @@ struct ConvImage {
     unsigned* amax_out;
     const unsigned* pcode_in;
     unsigned* pcode_out;
+    int in2_row0, in2_rows;
 };
 struct ConvBatch {
     ConvImage img[8];
@@ -138,15 +140,23 @@ hipError_t launch_bicubic_down_bwd(const float* gy, int C, int h, int w, int oh,
 
 // total variation: partial sums of |dx| and |dy| (NST_TV_BLOCKS x 2 doubles in `partial`)
 constexpr int TV_BLOCKS = 1024;
-hipError_t launch_tv_partial(const float* y, int C, int h, int w, double* partial, hipStream_t stream);
+// row window [row0, row0 + rows) of every channel (rows <= 0: all rows): the sums / the gradient of those rows only
+hipError_t launch_tv_partial(const float* y, int C, int h, int w, double* partial, hipStream_t stream, int row0 = 0,
+                             int rows = 0);
 // reduces the partials (fixed order), writes means to scal[0..1]; if grad: grad (+)= weight * d tv/dy
 hipError_t launch_tv_finish(const float* y, int C, int h, int w, const double* partial, float weight, float* grad,
-                            int accumulate, float* means, hipStream_t stream);
+                            int accumulate, float* means, hipStream_t stream, int row0 = 0, int rows = 0,
+                            const float* given_means = nullptr, double nx = 0, double ny = 0);
 
 // content: sum((a - t)^2) partials and, if g != nullptr, g = coef * (a - t) (coef = cw*2/n)
 constexpr int MSE_BLOCKS = 256;
 hipError_t launch_mse_grad(const float* a, const float* t, size_t n, float coef, float* g, double* partial,
                            hipStream_t stream);
+
+// scalar plumbing of the stripe closure (pixel_ops.hip)
+hipError_t launch_sum_doubles(const double* p, int n, int stride, int offset, float* out, hipStream_t stream);
+hipError_t launch_window_scalars(const float* sums, double nx, double ny, float* means, double* partial, int n,
+                                 hipStream_t stream);
 
 // prepare / unprepare
 hipError_t launch_prepare_img(const float* hwc, int h, int w, float* chw, hipStream_t stream);

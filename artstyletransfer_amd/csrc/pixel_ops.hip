@@ -321,13 +321,14 @@ hipError_t launch_bicubic_down_bwd(const float* gy, int C, int h, int w, int oh,
 
 // ------------------------------------------------------------------ total variation (math_utils.py:37-41)
 __global__ __launch_bounds__(256) void tv_partial_kernel(const float* __restrict__ y, int C, int h, int w,
-                                                         double* __restrict__ partial) {
+                                                         double* __restrict__ partial, int row0, int rows) {
     __shared__ double sh[4];
     // block b takes the image rows (c, r) with (c h + r) % TV_BLOCKS == b, a thread every 256th column: a fixed
     // assignment (reproducible sums) without any per-element division
     float sx = 0.f, sy = 0.f;
     for (int row = blockIdx.x; row < C * h; row += gridDim.x) {
         const int r = row % h;
+        if (rows > 0 && (unsigned)(r - row0) >= (unsigned)rows) continue;
         const float* line = y + (size_t)row * w;
         for (int x = threadIdx.x; x < w; x += blockDim.x) {
             const float v = line[x];
@@ -343,8 +344,8 @@ __global__ __launch_bounds__(256) void tv_partial_kernel(const float* __restrict
     }
 }
 
-hipError_t launch_tv_partial(const float* y, int C, int h, int w, double* partial, hipStream_t stream) {
-    hipLaunchKernelGGL(tv_partial_kernel, dim3(TV_BLOCKS), dim3(256), 0, stream, y, C, h, w, partial);
+hipError_t launch_tv_partial(const float* y, int C, int h, int w, double* partial, hipStream_t stream, int row0, int rows) {
+    hipLaunchKernelGGL(tv_partial_kernel, dim3(TV_BLOCKS), dim3(256), 0, stream, y, C, h, w, partial, row0, rows);
     return hipGetLastError();
 }
 
@@ -353,7 +354,8 @@ __device__ __forceinline__ float sgn(float v) { return (v > 0.f) ? 1.f : ((v < 0
 __global__ __launch_bounds__(256) void tv_finish_kernel(const float* __restrict__ y, int C, int h, int w,
                                                         const double* __restrict__ partial, float weight,
                                                         float* __restrict__ grad, int accumulate,
-                                                        float* __restrict__ means) {
+                                                        float* __restrict__ means, int row0, int rows,
+                                                        const float* __restrict__ given_means, double gnx, double gny) {
     __shared__ double sh[4];
     __shared__ float m[2];
     // every block re-reduces the TV_BLOCKS partials in the same fixed order
@@ -361,10 +363,11 @@ __global__ __launch_bounds__(256) void tv_finish_kernel(const float* __restrict_
     for (int b = threadIdx.x; b < TV_BLOCKS; b += blockDim.x) { px += partial[2 * b]; py += partial[2 * b + 1]; }
     const double tx = block_reduce_sum(px, sh);
     const double ty = block_reduce_sum(py, sh);
-    const double nx = (double)C * h * (w - 1), ny = (double)C * (h - 1) * w;
+    // (given_means: the means and element counts of a larger image of which y is a stripe)
+    const double nx = given_means ? gnx : (double)C * h * (w - 1), ny = given_means ? gny : (double)C * (h - 1) * w;
     if (threadIdx.x == 0) {
-        m[0] = (float)tx / (float)nx;
-        m[1] = (float)ty / (float)ny;
+        m[0] = given_means ? given_means[0] : (float)tx / (float)nx;
+        m[1] = given_means ? given_means[1] : (float)ty / (float)ny;
         if (blockIdx.x == 0 && blockIdx.y == 0 && means) { means[0] = m[0]; means[1] = m[1]; }
     }
     __syncthreads();
@@ -377,6 +380,7 @@ __global__ __launch_bounds__(256) void tv_finish_kernel(const float* __restrict_
     if (x >= w) return;
     for (int row = blockIdx.y; row < C * h; row += gridDim.y) {
         const int r = row % h;
+        if (rows > 0 && (unsigned)(r - row0) >= (unsigned)rows) continue;
         const size_t i = (size_t)row * w + x;
         const float v = y[i];
         float gx = 0.f, gyv = 0.f;
@@ -390,12 +394,43 @@ __global__ __launch_bounds__(256) void tv_finish_kernel(const float* __restrict_
 }
 
 hipError_t launch_tv_finish(const float* y, int C, int h, int w, const double* partial, float weight, float* grad,
-                            int accumulate, float* means, hipStream_t stream) {
-    const int rows = C * h;
+                            int accumulate, float* means, hipStream_t stream, int row0, int rows, const float* given_means,
+                            double nx, double ny) {
+    const int all_rows = C * h;
     // (every workgroup re-reduces the TV_BLOCKS partials first: a few rows per workgroup, but enough workgroups to
     // keep ~10 waves per SIMD in flight - with 96 row groups this kernel ran 2x slower)
-    const dim3 grid = grad ? dim3((w + 255) / 256, rows < 768 ? rows : 768) : dim3(1, 1);
-    hipLaunchKernelGGL(tv_finish_kernel, grid, dim3(256), 0, stream, y, C, h, w, partial, weight, grad, accumulate, means);
+    const dim3 grid = grad ? dim3((w + 255) / 256, all_rows < 768 ? all_rows : 768) : dim3(1, 1);
+    hipLaunchKernelGGL(tv_finish_kernel, grid, dim3(256), 0, stream, y, C, h, w, partial, weight, grad, accumulate, means,
+                       row0, rows, given_means, nx, ny);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ small scalar plumbing of the stripe (window) closure
+// out[0] = float(sum_k p[offset + k * stride]), k < n, fixed order
+__global__ __launch_bounds__(256) void sum_doubles_kernel(const double* __restrict__ p, int n, int stride, int offset,
+                                                          float* __restrict__ out) {
+    __shared__ double sh[4];
+    double t = 0.0;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) t += p[offset + (size_t)k * stride];
+    const double r = block_reduce_sum(t, sh);
+    if (threadIdx.x == 0) out[0] = (float)r;
+}
+hipError_t launch_sum_doubles(const double* p, int n, int stride, int offset, float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(sum_doubles_kernel, dim3(1), dim3(256), 0, stream, p, n, stride, offset, out);
+    return hipGetLastError();
+}
+// means[0] = sums[0] / nx, means[1] = sums[1] / ny (float divisions, as tv_finish does); partial[0] = sse, partial[1..n) = 0
+__global__ void window_scalars_kernel(const float* __restrict__ sums, float nx, float ny, float* __restrict__ means,
+                                      double* __restrict__ partial, int n) {
+    if (threadIdx.x == 0) {
+        means[0] = sums[1] / nx;
+        means[1] = sums[2] / ny;
+    }
+    for (int k = threadIdx.x; k < n; k += blockDim.x) partial[k] = (k == 0) ? (double)sums[0] : 0.0;
+}
+hipError_t launch_window_scalars(const float* sums, double nx, double ny, float* means, double* partial, int n,
+                                 hipStream_t stream) {
+    hipLaunchKernelGGL(window_scalars_kernel, dim3(1), dim3(256), 0, stream, sums, (float)nx, (float)ny, means, partial, n);
     return hipGetLastError();
 }
 

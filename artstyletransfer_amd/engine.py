@@ -115,6 +115,34 @@ class StyleEngine:
                                                          _ptr(losses), _stream(self.device)), "nst_closure_levels")
         return grad, losses
 
+    # ---- stripe (window) closure: this engine evaluates a horizontal stripe of a larger image (sharding.StripePlan)
+    def window_sums_count(self) -> int:
+        n = C.c_size_t()
+        _lib.check(None, self.lib.nst_window_sums_count(C.byref(n)), "nst_window_sums_count")
+        return n.value
+
+    def window_begin(self, xs: torch.Tensor, row0: int, rows: int, H0: int, sums: Optional[torch.Tensor] = None):
+        """Forward pass of the stripe image xs (1,3,ext,W0); returns the un-normalised Gram / content / TV sums of the
+        owned rows [row0, row0+rows) (see nst_window_begin)."""
+        _chk_dev(xs, self.device)
+        if sums is None:
+            sums = torch.empty(self.window_sums_count(), dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_window_begin(self.ctx, _ptr(xs), row0, rows, H0, _ptr(sums), _stream(self.device)),
+                   "nst_window_begin")
+        return sums
+
+    def window_end(self, xs: torch.Tensor, row0: int, rows: int, H0: int, cw: float, sw: float, tvw: float,
+                   sums: torch.Tensor):
+        """Backward pass for the loss terms of the owned rows, given the sums of ALL stripes; returns (d loss / d xs,
+        level loss row (total, content, style, tv, total)) (see nst_window_end)."""
+        _chk_dev(xs, self.device)
+        _chk_dev(sums, self.device)
+        gxs = torch.empty_like(xs)
+        losses = torch.empty(NST_LOSS_ROW + 1, dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_window_end(self.ctx, _ptr(xs), row0, rows, H0, cw, sw, tvw, _ptr(sums), _ptr(gxs),
+                                                     _ptr(losses), _stream(self.device)), "nst_window_end")
+        return gxs, losses
+
     def conv_mode(self) -> str:
         """How the 3x3 convolutions are evaluated (env NST_CONV at context creation): 'f16x2' (default: two scaled
         fp16 pieces per fp32 operand, 3 MFMAs per product block, fp32 accumulate), 'bf16x3' (three exact bf16

@@ -57,3 +57,39 @@ def aggregate_throughput(done: int, seconds: float, dist_mod=None, device=None):
     dist_mod.all_reduce(t, op=dist_mod.ReduceOp.MAX)
     dist_mod.all_reduce(d, op=dist_mod.ReduceOp.SUM)
     return int(round(d.item())), float(t.item())
+
+
+# ---- spatial sharding of the top pyramid level (SURVEY 8(e) partition B, halo recompute) -------------------------------
+STRIPE_HALO = 96        # rows: >= the receptive-field radius of relu5_1 (78), a multiple of 16
+
+
+class StripePlan:
+    """Rows of an H0-row image that rank `rank` of `world` owns, and the extended stripe it evaluates: the owned rows
+    plus STRIPE_HALO rows on each interior side.  Everything is a multiple of 16 (pooling alignment)."""
+
+    def __init__(self, H0: int, world: int, rank: int, halo: int = STRIPE_HALO):
+        if H0 % 16 or halo % 16:
+            raise ValueError("image height and halo must be multiples of 16")
+        units = H0 // 16
+        if world > units:
+            raise ValueError("more ranks than 16-row units")
+        lo = (units * rank // world) * 16
+        hi = (units * (rank + 1) // world) * 16
+        self.H0 = H0
+        self.own = (lo, hi)                                     # owned rows in image coordinates
+        self.ext = (max(0, lo - halo), min(H0, hi + halo))      # rows of the stripe image
+        self.row0 = lo - self.ext[0]                            # owned rows in stripe coordinates
+        self.rows = hi - lo
+
+    @property
+    def ext_rows(self) -> int:
+        return self.ext[1] - self.ext[0]
+
+    def cut(self, img):
+        """rows of a (1,3,H0,W) tensor that form the stripe image (a contiguous copy)"""
+        return img[:, :, self.ext[0]:self.ext[1], :].contiguous()
+
+    def add_into(self, full, stripe_grad):
+        """overlap-add of a stripe's gradient into the (1,3,H0,W) gradient"""
+        full[:, :, self.ext[0]:self.ext[1], :] += stripe_grad
+        return full

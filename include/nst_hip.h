@@ -159,6 +159,27 @@ int nst_noise_blend(nst_ctx* ctx, const float* content, const float* noise, int 
 /* dst = alpha * src (init_method 'random': 0.5 * noise, :351) */
 int nst_scale(nst_ctx* ctx, const float* src, float alpha, size_t n, float* dst, void* stream);
 
+/* ---- spatial sharding of one pyramid level: a context evaluates a horizontal STRIPE of a larger image ------------
+ * (SURVEY 8(e) partition B with halo recompute.  There is no counterpart in the reference; the quantities are those of
+ * neural_style_transfer.py:84-112 restricted to the rows a rank owns.)
+ * The context is configured with nst_job_configure(ctx, 1, ext_rows, W0) and its targets set with
+ * nst_level_set_targets(ctx, 0, <the same rows of the content image>, <the whole style image>, ...).  Its image `xs`
+ * (3, ext_rows, W0) is rows [e0, e0 + ext_rows) of the (3, H0, W0) image: the rows the rank owns,
+ * [row0, row0 + rows) in stripe coordinates, plus a halo on each interior side that covers the receptive field of
+ * relu5_1 (78 rows; 96 keeps everything a multiple of 16).  All row arguments are multiples of 16.
+ *   nst_window_begin: forward pass; writes to `sums` (nst_window_sums_count floats, device) the un-normalised Gram
+ *     sums of the five style maps, the content sum of squares and the two TV sums OVER THE OWNED ROWS.
+ *   The caller adds the `sums` of all stripes (one all-reduce).
+ *   nst_window_end: turns the summed `sums` into the style / content / TV terms of the FULL image (its normalisers),
+ *     runs the backward pass for the loss terms of the owned rows and writes d loss / d xs to gxs (3, ext_rows, W0);
+ *     the caller adds the stripes' gradients into the full image (overlap-add, one all-reduce).  losses[0..3] = (total,
+ *     content, style, tv) of the level, losses[4] = total - identical on every rank.
+ * Nothing else may run on the context between begin and end. */
+int nst_window_sums_count(size_t* count);
+int nst_window_begin(nst_ctx* ctx, const float* xs, int row0, int rows, int H0, float* sums, void* stream);
+int nst_window_end(nst_ctx* ctx, const float* xs, int row0, int rows, int H0, float content_weight, float style_weight,
+                   float tv_weight, float* sums, float* gxs, float* losses, void* stream);
+
 /* arithmetic of the 3x3 convolutions (environment NST_CONV at context creation):
  *   2 = "f16x2" (default): fp16 matrix pipe, both operands cut into two scaled fp16 pieces, 3 MFMAs per product
  *       block, main and cross terms in separate fp32 accumulators (error measured against fp64 = an fp32 MFMA's);

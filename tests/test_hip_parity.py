@@ -344,6 +344,50 @@ def test_f16x2_vs_exact_f32_mfma_random_geometries(vgg_weights, monkeypatch, geo
     assert rel_l2(g1, g0) < GRAD_RTOL
 
 
+@pytest.mark.parametrize("H0,W0,world", [(384, 256, 2), (384, 256, 3), (512, 208, 4)])
+def test_stripe_closure_adds_up_to_the_unsharded_closure(eng, vgg_weights, H0, W0, world):
+    """Spatial sharding of a level (sharding.StripePlan + nst_window_begin / nst_window_end): every rank evaluates its
+    rows plus a 96-row halo; Gram / content / TV sums are added over the stripes between the forward and the backward
+    pass, gradients are overlap-added.  Simulated here on one GPU, stripe after stripe: losses and gradient must be
+    those of the unsharded closure (the same tolerances as for any other pair of evaluations)."""
+    from artstyletransfer_amd.engine import StyleEngine
+    from artstyletransfer_amd.sharding import StripePlan
+    c = cpu_ref.synthetic_image(H0, W0, seed=1)
+    s = cpu_ref.synthetic_image(200, 176, seed=2)
+    ct, st = dev(cpu_ref.prepare_img(c)), dev(cpu_ref.prepare_img(s))
+    x = dev(cpu_ref.prepare_img((0.7 * c + 0.3 * cpu_ref.synthetic_image(H0, W0, seed=9)).astype(np.float32)))
+    eng.configure(1, H0, W0)
+    eng.set_targets(0, ct, st)
+    g_ref, l_ref = eng.closure(x, 1e3, 4e5, 1e2)
+    plans = [StripePlan(H0, world, r) for r in range(world)]
+    assert plans[0].own[0] == 0 and plans[-1].own[1] == H0 and all(a.own[1] == b.own[0] for a, b in zip(plans, plans[1:]))
+    engines = []
+    try:
+        sums = None
+        for pl in plans:
+            e = StyleEngine(vgg_weights, 0)
+            engines.append(e)
+            e.configure(1, pl.ext_rows, W0)
+            e.set_targets(0, pl.cut(ct), st)
+            part = e.window_begin(pl.cut(x), pl.row0, pl.rows, H0)
+            sums = part.clone() if sums is None else sums + part          # the all-reduce
+        grad = torch.zeros_like(x)
+        rows = []
+        for pl, e in zip(plans, engines):
+            gxs, losses = e.window_end(pl.cut(x), pl.row0, pl.rows, H0, 1e3, 4e5, 1e2, sums.clone())
+            pl.add_into(grad, gxs)                                          # the overlap-add
+            rows.append(losses.cpu().numpy())
+    finally:
+        for e in engines:
+            e.close()
+    l_ref = l_ref.cpu().numpy()
+    for r in rows:                      # every rank holds the same loss row of the full image
+        np.testing.assert_array_equal(r, rows[0])
+        assert float(r[-1]) == pytest.approx(float(l_ref[-1]), rel=1e-5)
+        check_rows(r[:4].reshape(1, 4), l_ref[:4].reshape(1, 4), 2e-5)
+    assert rel_l2(grad.cpu().numpy(), g_ref.cpu().numpy()) < GRAD_RTOL
+
+
 def test_closure_finite_difference(eng, vgg_weights):
     """Directional derivative of the HIP loss against its own gradient (size-independent property)."""
     c, s = _levels(64, 96, 2, 1), _levels(64, 96, 2, 2)
