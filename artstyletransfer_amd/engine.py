@@ -334,10 +334,51 @@ class PixelOptimizer:
                                                      _ptr(self._g), _ptr(self._l), self._hook, None),
                    "nst_opt_shard_levels")
 
+    def shard_stripes(self, rank: int, world: int, weights, content_t: torch.Tensor, style_t: torch.Tensor,
+                      dist_mod=None, group=None) -> None:
+        """Spatial sharding of the top level (SURVEY 8(e) partition B, halo recompute) on top of level sharding of the
+        rest: every rank evaluates a horizontal stripe of level 0 (its rows + a 96-row halo, a second engine) and its
+        share of the lower levels.  Per closure: one all-reduce of the Gram / content / TV sums between the stripe's
+        forward and backward pass, one of the pixel gradient and the loss rows at the end.  content_t / style_t: the
+        prepared (1,3,H0,W0) content and (1,3,hs,ws) style images of level 0."""
+        from . import sharding
+        if dist_mod is None:
+            import torch.distributed as dist_mod
+        e = self.engine
+        H, W = e.shape
+        plan = sharding.StripePlan(H, world, rank)
+        stripe = StyleEngine(weights, e.device)
+        stripe.configure(1, plan.ext_rows, W)
+        stripe.set_targets(0, plan.cut(content_t), style_t.contiguous())
+        self._stripe, self._plan = stripe, plan
+        self._g = torch.zeros((1, 3, H, W), dtype=torch.float32, device=e.device)
+        self._l = torch.zeros(self.row, dtype=torch.float32, device=e.device)
+        # lower levels: level l >= 1 on rank l % world; level 0 is nobody's in the level mask (its stripes are added here)
+        mask = 0
+        for l in range(1, e.levels):
+            if l % world == rank:
+                mask |= 1 << l
+
+        def hook(_user):
+            x, (cw, sw, tvw) = self._x, self._w
+            xs = plan.cut(x)
+            sums = stripe.window_begin(xs, plan.row0, plan.rows, H)
+            dist_mod.all_reduce(sums, op=dist_mod.ReduceOp.SUM, group=group)
+            gxs, row = stripe.window_end(xs, plan.row0, plan.rows, H, cw, sw, tvw, sums)
+            plan.add_into(self._g, gxs)
+            if rank == 0:                      # every rank holds the same level-0 row: one contributor
+                self._l[0:4] = row[0:4]
+            sharding.allreduce_closure(self._g, self._l, dist_mod, group)
+
+        self._hook = _lib.REDUCE_HOOK(hook)
+        _lib.check(e.ctx, e.lib.nst_opt_shard_levels(self.h, mask, _ptr(self._g), _ptr(self._l), self._hook, None),
+                   "nst_opt_shard_levels")
+
     def step(self, x: torch.Tensor, cw: float, sw: float, tvw: float, want_losses: bool = True):
         """One optimizer.step(closure). Returns (StepInfo, rows[closures, 4*levels+1] or None)."""
         e = self.engine
         _chk_dev(x, e.device)
+        self._x, self._w = x, (cw, sw, tvw)          # what a stripe hook evaluates (x is updated in place)
         info = StepInfo()
         ptr = C.c_void_p(self._rows.ctypes.data) if want_losses else C.c_void_p(0)
         _lib.check(e.ctx, e.lib.nst_opt_step(self.h, _ptr(x), cw, sw, tvw, ptr, self.cap, C.byref(info),

@@ -175,7 +175,7 @@ def main():
     ap.add_argument("--time-all-kernels", action="store_true", help="event pairs around every launch (slower)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
-    ap.add_argument("--mode", default="jobs", choices=["jobs", "levels"],
+    ap.add_argument("--mode", default="jobs", choices=["jobs", "levels", "stripes"],
                     help="N>1: 'jobs' = one independent job per GPU (weak scaling, no collective); 'levels' = ONE "
                          "job, pyramid levels sharded over the ranks, RCCL all-reduce of the pixel gradient per "
                          "closure (BASELINE config 4, strong scaling, capped at 1.33x by the 75/19/5/1 % split)")
@@ -200,12 +200,16 @@ def main():
             dist.init_process_group(args.dist_backend)
 
     from artstyletransfer_amd.engine import PixelOptimizer
-    sharded = world > 1 and args.mode == "levels"
+    sharded = world > 1 and args.mode in ("levels", "stripes")
     eng, x, cfg, job_host = build_job(args.levels, 0 if sharded else rank, local_rank)
     cfg.optimizer = args.optimizer
     opt = PixelOptimizer(eng, args.optimizer, 10.0, 1)
-    if sharded:
+    if sharded and args.mode == "levels":
         opt.shard_levels(rank, world, dist)
+    elif sharded:
+        # the top level cut into horizontal stripes (+ halo), the lower levels dealt out by level
+        prep = lambda a: eng.prepare_img(torch.from_numpy(a).to(x.device))
+        opt.shard_stripes(rank, world, job_host[3], prep(job_host[0][0]), prep(job_host[1][0]), dist)
     cw, sw, tvw = cfg.content_weight, cfg.style_weight, cfg.tv_weight
     H, W = eng.shape
     # per-step image yield as NeuralStyleTransfer.process does it: un-prepare on the device, D2H into pinned
@@ -288,7 +292,10 @@ def main():
                                    f"{'off' if args.no_yield else 'on'}",
                        "iter": "one closure evaluation (forward + losses + backward of every level) + its share of the optimiser update",
                        "parallelism": ("1 GPU" if world == 1 else
-                                       f"levels sharded over {world} ranks, RCCL all-reduce of the pixel gradient"
+                                       (f"levels sharded over {world} ranks, RCCL all-reduce of the pixel gradient"
+                                        if args.mode == "levels" else
+                                        f"top level in {world} stripes (+96-row halo), lower levels by level; all-reduce of the "
+                                        f"Gram/content/TV sums and of the pixel gradient per closure")
                                        if sharded else "1 job per GPU, no collective"),
                        "final_loss": float(last_rows[-1][-1]) if last_rows is not None else None,
                        "job_setup_ms_on_device": round(getattr(cfg, "job_setup_ms", 0.0), 1)},

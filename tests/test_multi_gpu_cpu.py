@@ -91,3 +91,44 @@ def test_level_sharding_and_aggregation_gloo_world2():
     assert res["loss"] == pytest.approx(res["full_loss"], rel=1e-6)
     np.testing.assert_allclose(np.array(res["rows"]), np.array(res["full_rows"]), rtol=1e-6)
     assert res["done"] == 21 and res["dt"] == pytest.approx(2.0)
+
+
+def test_stripe_plan_covers_the_image_and_keeps_alignment():
+    """Spatial sharding plan (sharding.StripePlan): owned rows tile the image without gaps, every boundary is a
+    multiple of 16 (pooling alignment down to relu5_1), interior sides carry the 96-row halo."""
+    from artstyletransfer_amd.sharding import STRIPE_HALO, StripePlan
+    for H0 in (256, 1024, 1040, 2048):
+        for world in (1, 2, 3, 4, 8):
+            plans = [StripePlan(H0, world, r) for r in range(world)]
+            assert plans[0].own[0] == 0 and plans[-1].own[1] == H0
+            for a, b in zip(plans, plans[1:]):
+                assert a.own[1] == b.own[0]
+            for p in plans:
+                lo, hi = p.own
+                assert lo % 16 == 0 and hi % 16 == 0 and hi > lo
+                assert p.ext[0] % 16 == 0 and p.ext[1] % 16 == 0
+                assert p.ext[0] == max(0, lo - STRIPE_HALO) and p.ext[1] == min(H0, hi + STRIPE_HALO)
+                assert p.row0 == lo - p.ext[0] and p.rows == hi - lo and p.ext_rows == p.ext[1] - p.ext[0]
+    import pytest
+    with pytest.raises(ValueError):
+        StripePlan(1000, 2, 0)          # not a multiple of 16
+    with pytest.raises(ValueError):
+        StripePlan(64, 8, 0)            # fewer 16-row units than ranks
+
+
+def test_stripe_plan_cut_and_overlap_add_round_trip():
+    import torch
+    from artstyletransfer_amd.sharding import StripePlan
+    H0, W = 512, 48
+    img = torch.arange(3 * H0 * W, dtype=torch.float32).reshape(1, 3, H0, W)
+    acc = torch.zeros_like(img)
+    cover = torch.zeros(H0)
+    for r in range(3):
+        p = StripePlan(H0, 3, r)
+        xs = p.cut(img)
+        assert xs.shape == (1, 3, p.ext_rows, W) and xs.is_contiguous()
+        own = torch.zeros_like(xs)
+        own[:, :, p.row0:p.row0 + p.rows, :] = xs[:, :, p.row0:p.row0 + p.rows, :]     # a "gradient" on the owned rows only
+        p.add_into(acc, own)
+        cover[p.own[0]:p.own[1]] += 1
+    assert torch.equal(acc, img) and torch.equal(cover, torch.ones(H0))

@@ -10,15 +10,19 @@ dist = None
 if world > 1:
     import torch.distributed as dist
     dist.init_process_group("gloo")
-eng, x, cfg, _ = bench.build_job(3, 0, 0)
+mode = sys.argv[1] if len(sys.argv) > 1 else "levels"          # levels | stripes
+eng, x, cfg, host = bench.build_job(3, 0, 0)
 opt = PixelOptimizer(eng, "lbfgs", 10.0, 1)
-if world > 1:
+if world > 1 and mode == "levels":
     opt.shard_levels(rank, world, dist)
+elif world > 1:
+    prep = lambda a: eng.prepare_img(torch.from_numpy(a).to(x.device))
+    opt.shard_stripes(rank, world, host[3], prep(host[0][0]), prep(host[1][0]), dist)
 out = []
 for k in range(5):
     info, rows = opt.step(x, cfg.content_weight, cfg.style_weight, cfg.tv_weight)
     out += [float(r[-1]) for r in rows] + [int(info.accepted)]
 if rank == 0:
-    print("world", world, "totals/accept:", out, "x checksum", float(x.double().sum()))
+    print("world", world, mode, "totals/accept:", out, "x checksum", float(x.double().sum()))
 if dist is not None:
     dist.barrier(); dist.destroy_process_group()
