@@ -505,6 +505,9 @@ struct Window {
     int row0, rows, H0;
     float* sums;          // begin: out;  end: in (summed over the stripes)
 };
+// owned rows at a layer of stride 2^sc: [row0 >> sc, (row0 + rows) >> sc) (the bottom stripe may end on a ragged row)
+inline int win_r0(const Window& w, int sc) { return w.row0 >> sc; }
+inline int win_nr(const Window& w, int sc) { return ((w.row0 + w.rows) >> sc) - (w.row0 >> sc); }
 constexpr size_t kWinGramOff[5] = {0, 64 * 64, 64 * 64 + 128 * 128, 64 * 64 + 128 * 128 + 256 * 256,
                                    64 * 64 + 128 * 128 + 256 * 256 + 512 * 512};
 constexpr size_t kWinScalarOff = 64 * 64 + 128 * 128 + 256 * 256 + 2 * 512 * 512;    // content SSE, TV x, TV y
@@ -615,7 +618,7 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
             im.out = cur[k]; im.H = a.h[l]; im.W = a.w[l];
             im.in2 = a.act[l]; im.wt2_f32 = L.S[4]; im.amax_in2 = amax_act(a, l); im.amax_w2 = amax_S(a, 4);
             im.bits_in = a.bits[l]; im.amax_out = amax_grad(a, l);
-            if (win) { im.in2_row0 = win->row0 >> kScale[l]; im.in2_rows = win->rows >> kScale[l]; }
+            if (win) { im.in2_row0 = win_r0(*win, kScale[l]); im.in2_rows = win_nr(*win, kScale[l]); }
             flops += conv_flops(im.H, im.W, b.Cin2, b.Cout, 1);
         }
         Timer t(ctx, s, K_GRAM, flops);
@@ -657,14 +660,14 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
             if (style_q >= 0) {
                 im.in2 = a.act[m]; im.wt2_bf = L.S_bf[style_q];
                 im.wt2_f32 = L.S[style_q]; im.amax_in2 = amax_act(a, m); im.amax_w2 = amax_S(a, style_q);
-                if (win) { im.in2_row0 = win->row0 >> kScale[m]; im.in2_rows = win->rows >> kScale[m]; }
+                if (win) { im.in2_row0 = win_r0(*win, kScale[m]); im.in2_rows = win_nr(*win, kScale[m]); }
                 flops += conv_flops(a.h[m], a.w[m], kCout[m], kCout[m], 1);
             } else if (m == kContentLayer) {
                 Timer t(ctx, s, K_OTHER, 0);
                 if (win) {
                     // content gradient on the owned rows only (zero elsewhere), normalised by the full image's size
-                    const size_t off = (size_t)(win->row0 >> kScale[m]) * a.w[m] * kCout[m];
-                    const size_t cnt = (size_t)(win->rows >> kScale[m]) * a.w[m] * kCout[m];
+                    const size_t off = (size_t)win_r0(*win, kScale[m]) * a.w[m] * kCout[m];
+                    const size_t cnt = (size_t)win_nr(*win, kScale[m]) * a.w[m] * kCout[m];
                     const double n_all = (double)(win->H0 >> kScale[m]) * a.w[m] * kCout[m];
                     HIPCHK(ctx, hipMemsetAsync(oth[k], 0, L.content_n * sizeof(float), s));
                     HIPCHK(ctx, launch_mse_grad(a.act[m] + off, L.content_t + off, cnt, (float)((double)cw * 2.0 / n_all),
@@ -1137,8 +1140,11 @@ static int window_check(nst_ctx* ctx, const float* xs, int row0, int rows, int H
     LevelWs& L = ctx->lv[0];
     if (!L.targets) return fail(ctx, NST_E_STATE, "targets of the stripe not set");
     if (!xs) return fail(ctx, NST_E_ARG, "null buffer");
-    if (row0 < 0 || rows < 16 || row0 % 16 || rows % 16 || row0 + rows > L.h || H0 < L.h || H0 % 16 || L.h % 16 || L.w % 16)
-        return fail(ctx, NST_E_ARG, "stripe rows must be multiples of 16 inside the stripe image, image sizes multiples of 16");
+    // boundaries between stripes on multiples of 16 rows (pooling alignment); only a stripe that ends with the stripe
+    // image - the bottom of the full image - may own a ragged last row group
+    const bool to_bottom = (row0 + rows == L.h);
+    if (row0 < 0 || rows < 16 || row0 % 16 || (!to_bottom && rows % 16) || row0 + rows > L.h || H0 < L.h)
+        return fail(ctx, NST_E_ARG, "stripe rows: start and interior boundaries on multiples of 16 rows, inside the stripe image");
     if ((size_t)L.h * L.w * 64 * 4 >= 0xFFFFFF00ull) return fail(ctx, NST_E_ARG, "stripe image too large for the f16x2 kernels");
     return NST_OK;
 }
@@ -1157,8 +1163,8 @@ int nst_window_begin(nst_ctx* ctx, const float* xs, int row0, int rows, int H0, 
     // un-normalised Gram sums of the owned rows
     for (int q = 0; q < 5; ++q) {
         const int l = kStyleLayer[q], C = kCout[l];
-        const size_t off = (size_t)(row0 >> kScale[l]) * a.w[l] * C;
-        const size_t N = (size_t)(rows >> kScale[l]) * a.w[l];
+        const size_t off = (size_t)win_r0(win, kScale[l]) * a.w[l] * C;
+        const size_t N = (size_t)win_nr(win, kScale[l]) * a.w[l];
         const int ns = gram_nsplit(C, N);
         HIPCHK(ctx, launch_gram_partial(a.act[l] + off, N, C, ns, amax_act(a, l), L.gram_part, s));
         HIPCHK(ctx, launch_gram_finish(L.gram_part, gram_nslabs(C, ns), C, 1.f, nullptr, 0.f, sums + kWinGramOff[q], nullptr, nullptr,
@@ -1167,8 +1173,8 @@ int nst_window_begin(nst_ctx* ctx, const float* xs, int row0, int rows, int H0, 
     // content: sum of squared differences over the owned rows
     {
         const int m = kContentLayer;
-        const size_t off = (size_t)(row0 >> kScale[m]) * a.w[m] * kCout[m];
-        const size_t cnt = (size_t)(rows >> kScale[m]) * a.w[m] * kCout[m];
+        const size_t off = (size_t)win_r0(win, kScale[m]) * a.w[m] * kCout[m];
+        const size_t cnt = (size_t)win_nr(win, kScale[m]) * a.w[m] * kCout[m];
         HIPCHK(ctx, launch_mse_grad(a.act[m] + off, L.content_t + off, cnt, 0.f, nullptr, L.content_partial, s));
         HIPCHK(ctx, launch_sum_doubles(L.content_partial, MSE_BLOCKS, 1, 0, sums + kWinScalarOff, s));
     }

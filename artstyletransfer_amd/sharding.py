@@ -65,16 +65,16 @@ STRIPE_HALO = 96        # rows: >= the receptive-field radius of relu5_1 (78), a
 
 class StripePlan:
     """Rows of an H0-row image that rank `rank` of `world` owns, and the extended stripe it evaluates: the owned rows
-    plus STRIPE_HALO rows on each interior side.  Everything is a multiple of 16 (pooling alignment)."""
+    plus STRIPE_HALO rows on each interior side.  Boundaries between stripes are multiples of 16 (pooling alignment)."""
 
     def __init__(self, H0: int, world: int, rank: int, halo: int = STRIPE_HALO):
-        if H0 % 16 or halo % 16:
-            raise ValueError("image height and halo must be multiples of 16")
+        if halo % 16:
+            raise ValueError("the halo must be a multiple of 16 rows")
         units = H0 // 16
         if world > units:
             raise ValueError("more ranks than 16-row units")
         lo = (units * rank // world) * 16
-        hi = (units * (rank + 1) // world) * 16
+        hi = H0 if rank == world - 1 else (units * (rank + 1) // world) * 16     # the bottom stripe takes a ragged remainder
         self.H0 = H0
         self.own = (lo, hi)                                     # owned rows in image coordinates
         self.ext = (max(0, lo - halo), min(H0, hi + halo))      # rows of the stripe image

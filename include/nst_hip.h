@@ -166,7 +166,8 @@ int nst_scale(nst_ctx* ctx, const float* src, float alpha, size_t n, float* dst,
  * nst_level_set_targets(ctx, 0, <the same rows of the content image>, <the whole style image>, ...).  Its image `xs`
  * (3, ext_rows, W0) is rows [e0, e0 + ext_rows) of the (3, H0, W0) image: the rows the rank owns,
  * [row0, row0 + rows) in stripe coordinates, plus a halo on each interior side that covers the receptive field of
- * relu5_1 (78 rows; 96 keeps everything a multiple of 16).  All row arguments are multiples of 16.
+ * relu5_1 (78 rows; 96 keeps the boundaries multiples of 16).  row0 and the boundaries between stripes are multiples
+ * of 16 (pooling alignment); only the bottom stripe may own a ragged last row group.
  *   nst_window_begin: forward pass; writes to `sums` (nst_window_sums_count floats, device) the un-normalised Gram
  *     sums of the five style maps, the content sum of squares and the two TV sums OVER THE OWNED ROWS.
  *   The caller adds the `sums` of all stripes (one all-reduce).

@@ -344,7 +344,7 @@ def test_f16x2_vs_exact_f32_mfma_random_geometries(vgg_weights, monkeypatch, geo
     assert rel_l2(g1, g0) < GRAD_RTOL
 
 
-@pytest.mark.parametrize("H0,W0,world", [(384, 256, 2), (384, 256, 3), (512, 208, 4)])
+@pytest.mark.parametrize("H0,W0,world", [(384, 256, 2), (384, 256, 3), (512, 208, 4), (390, 250, 2), (471, 183, 3)])
 def test_stripe_closure_adds_up_to_the_unsharded_closure(eng, vgg_weights, H0, W0, world):
     """Spatial sharding of a level (sharding.StripePlan + nst_window_begin / nst_window_end): every rank evaluates its
     rows plus a 96-row halo; Gram / content / TV sums are added over the stripes between the forward and the backward
