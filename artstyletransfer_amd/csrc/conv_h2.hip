@@ -284,14 +284,24 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             const_cast<float*>(src), 0, (unsigned)((size_t)p.H * p.W * cin * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<float*>(wts), 0, (unsigned)((size_t)p.Cout * cin * 4), 0x00020000);
-        unsigned a_voff[C::A_PER_T], b_voff[C::B_PER_T];
+        // A 1-tap source reads the centre of the patch only: stage just the TH x 16 output pixels (no halo ring,
+        // no division by the patch width) - the Gram stages are bound by this staging, not by their MFMAs.
+        constexpr int G_PER_T = TH * C::TW * QP / C::NT;
+        static_assert(TH * C::TW * QP % C::NT == 0 && G_PER_T <= C::A_PER_T, "centre units divide evenly");
+        unsigned a_voff[G_PER_T], b_voff[C::B_PER_T];
+        int g_lds[G_PER_T];
 #pragma unroll
-        for (int i = 0; i < C::A_PER_T; ++i) {
-            a_voff[i] = a_voff_of(i, tid, cin, false);
+        for (int i = 0; i < G_PER_T; ++i) {
+            const int u = tid + i * C::NT;
+            const int pix = u / QP, q = u % QP;
+            const int py = pix >> 4, px = pix & 15;
+            const int gy = y0 + py, gx = x0 + px;
+            bool ok = (gy < p.H) & (gx < p.W);
             // row window of the second source (a job evaluated on a stripe of a larger image adds the Gram backward on
             // the rows it owns only): rows outside read as zeros
-            const int gy = y0 - 1 + ((tid + i * C::NT) / QP) / C::PW;
-            if (p.in2_rows > 0 && (unsigned)(gy - p.in2_row0) >= (unsigned)p.in2_rows) a_voff[i] = 0xFFFFFF00u;
+            if (p.in2_rows > 0) ok = ok & ((unsigned)(gy - p.in2_row0) < (unsigned)p.in2_rows);
+            a_voff[i] = ok ? (unsigned)(((gy * p.W + gx) * cin + q * 4) * 4) : 0xFFFFFF00u;
+            g_lds[i] = (py + 1) * C::PROWB + (px + 1) * ROWB + q * 8;
         }
 #pragma unroll
         for (int i = 0; i < C::B_PER_T; ++i) {
@@ -300,14 +310,24 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         }
         auto load = [&](int chunk) {
 #pragma unroll
-            for (int i = 0; i < C::A_PER_T; ++i)
+            for (int i = 0; i < G_PER_T; ++i)
                 ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, a_voff[i], chunk * KC * 4, 0));
 #pragma unroll
             for (int i = 0; i < C::B_PER_T; ++i)
                 rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, b_voff[i], (n0 * cin + chunk * KC) * 4, 0);
         };
+        auto store_centre = [&](unsigned char* dstA) {
+#pragma unroll
+            for (int i = 0; i < G_PER_T; ++i) {
+                u32x2 hi, lo;
+                cut2x4(ra[i], sa, hi, lo);
+                unsigned char* row = dstA + g_lds[i];
+                *reinterpret_cast<u32x2*>(row) = hi;
+                *reinterpret_cast<u32x2*>(row + PIECEB) = lo;
+            }
+        };
         load(0);
-        store_a(ldsA, sa, ra, 0, C::A_PER_T, tid);
+        store_centre(ldsA);
         store_b_f32(ldsB, sw, tid);
         if (nch > 1) load(1);
         __syncthreads();
@@ -315,7 +335,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             const int cb = c & 1;
             if (c + 1 < nch) {
                 // the other buffers were last read in stage c-1, which every wave has left
-                store_a(ldsA + (cb ^ 1) * C::A_BYTES, sa, ra, 0, C::A_PER_T, tid);
+                store_centre(ldsA + (cb ^ 1) * C::A_BYTES);
                 store_b_f32(ldsB + (cb ^ 1) * C::B_BYTES, sw, tid);
                 if (c + 2 < nch) load(c + 2);
             }
