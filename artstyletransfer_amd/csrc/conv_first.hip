@@ -172,17 +172,32 @@ __global__ __launch_bounds__(256) void conv1_1_dgrad_kernel(const float* __restr
     // VALU instructions per (gradient value) instead of three on a VALU-bound kernel
     f32x2 a01 = {0.f, 0.f};
     float a2 = 0.f;
-    for (int chunk = 0; chunk < 64 / D_KC; ++chunk) {
-        if (chunk) __syncthreads();
-        for (int u = tid; u < D_UNITS; u += 256) {
+    // the halo patch of a 32-channel slice: global -> registers -> LDS; the next slice's loads are issued before this
+    // slice is multiplied, so that only the first one is exposed
+    constexpr int D_PER_T = (D_UNITS + 255) / 256;
+    f32x4 stage[D_PER_T];
+    auto fetch = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < D_PER_T; ++i) {
+            const int u = tid + i * 256;
             const int pix = u / (D_KC / 4), q = u % (D_KC / 4);
             const int gy = y0 - 1 + pix / D_P, gxx = x0 - 1 + pix % D_P;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gy >= 0 && gy < H && gxx >= 0 && gxx < W)
+            if (u < D_UNITS && gy >= 0 && gy < H && gxx >= 0 && gxx < W)
                 v = *reinterpret_cast<const f32x4*>(g + ((size_t)gy * W + gxx) * 64 + chunk * D_KC + q * 4);
-            *reinterpret_cast<f32x4*>(patch + pix * D_RS + q * 4) = v;
+            stage[i] = v;
+        }
+    };
+    fetch(0);
+    for (int chunk = 0; chunk < 64 / D_KC; ++chunk) {
+        if (chunk) __syncthreads();
+#pragma unroll
+        for (int i = 0; i < D_PER_T; ++i) {
+            const int u = tid + i * 256;
+            if (u < D_UNITS) *reinterpret_cast<f32x4*>(patch + (u / (D_KC / 4)) * D_RS + (u % (D_KC / 4)) * 4) = stage[i];
         }
         __syncthreads();
+        if (chunk + 1 < 64 / D_KC) fetch(chunk + 1);
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const float* row = patch + ((py + t / 3) * D_P + px + t % 3) * D_RS;
