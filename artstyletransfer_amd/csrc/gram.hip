@@ -474,8 +474,18 @@ __device__ __forceinline__ void gram_finish_body(const float* __restrict__ part,
     }
     const bool mine = e < CC && (!tri || j >= i);
     float s = 0.f;
-    if (mine)
-        for (int k = grp; k < nslabs; k += 8) s += part[(size_t)k * CC + e];
+    if (mine) {
+        // eight slab reads in flight per lane (the adds stay in slab order): this pass is latency-bound otherwise
+        int k = grp;
+        for (; k + 56 < nslabs; k += 64) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + 8 * j) * CC + e];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+        }
+        for (; k < nslabs; k += 8) s += part[(size_t)k * CC + e];
+    }
     sh[grp][el] = s;
     __syncthreads();
     if (grp == 0) {

@@ -504,59 +504,78 @@ hipError_t launch_unprepare_img(const float* chw, int h, int w, float* hwc, hipS
 }
 
 // ------------------------------------------------------------------ loss rows (neural_style_transfer.py:95-110, :179-185)
-__global__ __launch_bounds__(256) void loss_assemble_kernel(LossAssembly la) {
+// one workgroup per level: the six sums of a level (content + 5 style) go through ONE pair of barriers (each sum
+// keeps its own fixed order: strided per-thread share in index order, wave tree, waves in order)
+__global__ __launch_bounds__(256) void loss_rows_kernel(LossAssembly la) {
 #pragma clang fp contract(off)
-    __shared__ double sh[4];
-    __shared__ float tot;
-    bool first = true;
-    for (int l = 0; l < la.levels; ++l) {
-        const LevelLossInputs& in = la.lv[l];
-        if (!in.owned) {
-            if (threadIdx.x < 4) la.out[4 * l + threadIdx.x] = 0.f;
-            continue;
-        }
-        const double cs = block_reduce_sum(threadIdx.x < MSE_BLOCKS ? in.content_partial[threadIdx.x] : 0.0, sh);
-        double ss[5];
-        for (int k = 0; k < 5; ++k) {
-            // C*C/32 partials: each thread adds its strided share in index order, then the fixed tree
-            const int nb = (in.style_c[k] * in.style_c[k] + 31) / 32;
-            // (loads issued together, adds in index order: the latency of 32 dependent-looking loads was 100 us)
-            double v[32];
-#pragma unroll
-            for (int j = 0; j < 32; ++j) {
-                const int b = threadIdx.x + j * 256;
-                v[j] = b < nb ? in.style_partial[k][b] : 0.0;
-            }
-            double t = 0.0;
-#pragma unroll
-            for (int j = 0; j < 32; ++j) t += v[j];
-            for (int b = threadIdx.x + 32 * 256; b < nb; b += 256) t += in.style_partial[k][b];
-            ss[k] = block_reduce_sum(t, sh);
-        }
-        if (threadIdx.x == 0) {
-            const float content = (float)(cs / (double)in.content_n);
-            float style = 0.f;
-            for (int k = 0; k < 5; ++k) style = style + (float)(ss[k] / ((double)in.style_c[k] * in.style_c[k]));
-            style = style / 5.f;
-            const float mx = in.tv_means[0], my = in.tv_means[1];
-            const float tv = mx * mx + my * my;
-            // cw*content + sw*style + tvw*tv, each product and sum rounded (contraction is off here)
-            const float t0 = la.cw * content, t1 = la.sw * style, t2 = la.tvw * tv;
-            const float total = (t0 + t1) + t2;
-            la.out[4 * l + 0] = total;
-            la.out[4 * l + 1] = content;
-            la.out[4 * l + 2] = style;
-            la.out[4 * l + 3] = tv;
-            tot = first ? total : (1.0f * tot + total);
-        }
-        first = false;
-        __syncthreads();
+    __shared__ double sh[6][4];
+    const int l = blockIdx.x;
+    const LevelLossInputs& in = la.lv[l];
+    if (!in.owned) {
+        if (threadIdx.x < 4) la.out[4 * l + threadIdx.x] = 0.f;
+        return;
     }
-    if (threadIdx.x == 0) la.out[4 * la.levels] = first ? 0.f : tot;
+    double v[6];
+    v[0] = threadIdx.x < MSE_BLOCKS ? in.content_partial[threadIdx.x] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        // C*C/32 partials: each thread adds its strided share in index order, then the fixed tree
+        const int nb = (in.style_c[k] * in.style_c[k] + 31) / 32;
+        double p[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+            const int b = threadIdx.x + j * 256;
+            p[j] = b < nb ? in.style_partial[k][b] : 0.0;
+        }
+        double t = 0.0;
+#pragma unroll
+        for (int j = 0; j < 32; ++j) t += p[j];
+        for (int b = threadIdx.x + 32 * 256; b < nb; b += 256) t += in.style_partial[k][b];
+        v[k + 1] = t;
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        double x = v[q];
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) sh[q][w] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r[6];
+        for (int q = 0; q < 6; ++q) { r[q] = 0.0; for (int i = 0; i < 4; ++i) r[q] += sh[q][i]; }
+        const float content = (float)(r[0] / (double)in.content_n);
+        float style = 0.f;
+        for (int k = 0; k < 5; ++k) style = style + (float)(r[k + 1] / ((double)in.style_c[k] * in.style_c[k]));
+        style = style / 5.f;
+        const float mx = in.tv_means[0], my = in.tv_means[1];
+        const float tv = mx * mx + my * my;
+        // cw*content + sw*style + tvw*tv, each product and sum rounded (contraction is off here)
+        const float t0 = la.cw * content, t1 = la.sw * style, t2 = la.tvw * tv;
+        la.out[4 * l + 0] = (t0 + t1) + t2;
+        la.out[4 * l + 1] = content;
+        la.out[4 * l + 2] = style;
+        la.out[4 * l + 3] = tv;
+    }
+}
+// total = sum of the owned levels' totals in level order (neural_style_transfer.py:179-185)
+__global__ void loss_total_kernel(LossAssembly la) {
+#pragma clang fp contract(off)
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bool first = true;
+    float tot = 0.f;
+    for (int l = 0; l < la.levels; ++l) {
+        if (!la.lv[l].owned) continue;
+        const float total = la.out[4 * l];
+        tot = first ? total : (1.0f * tot + total);
+        first = false;
+    }
+    la.out[4 * la.levels] = first ? 0.f : tot;
 }
 
 hipError_t launch_loss_assemble(const LossAssembly& la, hipStream_t stream) {
-    hipLaunchKernelGGL(loss_assemble_kernel, dim3(1), dim3(256), 0, stream, la);
+    hipLaunchKernelGGL(loss_rows_kernel, dim3(la.levels), dim3(256), 0, stream, la);
+    hipLaunchKernelGGL(loss_total_kernel, dim3(1), dim3(64), 0, stream, la);
     return hipGetLastError();
 }
 
