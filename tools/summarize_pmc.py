@@ -3,7 +3,7 @@
     python tools/summarize_pmc.py traffic <FETCH_SIZE dir> <WRITE_SIZE dir> <out.txt> <out.json>
     python tools/summarize_pmc.py mfma <counter dir> <out.txt>
 
-Window = the dispatches of the LAST closure of the run (from after the previous loss_assemble_kernel up to and
+Window = the dispatches of the LAST closure of the run (from after the previous loss_total_kernel up to and
 including the last one).  FETCH_SIZE / WRITE_SIZE are in KiB (rocprofv3 derives them as requests x size / 1024); on gfx950 FETCH_SIZE tallies the 128-B requests of
 wide streaming reads as 64 B (MI355X_MICROARCH.md, HBM section), so fetch bytes are doubled."""
 import csv
@@ -35,7 +35,7 @@ def last_closure(rows):
     for r in rows:
         disp.setdefault(int(r["Dispatch_Id"]), r["Kernel_Name"])
     ids = list(disp)
-    marks = [i for i, d in enumerate(ids) if "loss_assemble" in disp[d]]
+    marks = [i for i, d in enumerate(ids) if "loss_total" in disp[d] or "loss_assemble" in disp[d]]
     if len(marks) < 2:
         raise SystemExit("need at least two closures in the trace")
     return ids[marks[-2] + 1: marks[-1] + 1]
