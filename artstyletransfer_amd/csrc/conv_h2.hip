@@ -160,10 +160,10 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         const int gx = x0 - 1 + pc;
         // (unsigned compares fold the >= 0 tests; bitwise & keeps this a select instead of short-circuit branches)
         bool ok = (u < C::A_UNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
-        if (!pooled) return ok ? (unsigned)(((gy * p.W + gx) * cin + (u % QP) * 4) * 4) : 0xFFFFFF00u;
+        if (!pooled) return ok ? ((unsigned)(gy * p.W + gx) * (unsigned)cin + (unsigned)(u % QP) * 4u) * 4u : 0xFFFFFF00u;
         const int PH2 = p.H >> 1, PW2 = p.W >> 1;
         ok = ok & ((gy >> 1) < PH2) & ((gx >> 1) < PW2);      // the odd last row / column belongs to no window
-        return ok ? (unsigned)((((gy >> 1) * PW2 + (gx >> 1)) * cin + (u % QP) * 4) * 4) : 0xFFFFFF00u;
+        return ok ? ((unsigned)((gy >> 1) * PW2 + (gx >> 1)) * (unsigned)cin + (unsigned)(u % QP) * 4u) * 4u : 0xFFFFFF00u;
     };
     // byte offset of the arg-max code word of patch unit i: [pooled pixel][32-channel group][window position]
     auto a_coff_of = [&](int i, int to, int cin) -> unsigned {
@@ -176,7 +176,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         const int PH2 = p.H >> 1, PW2 = p.W >> 1;
         const bool ok = (u < C::A_UNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W) &
                         ((gy >> 1) < PH2) & ((gx >> 1) < PW2);
-        return ok ? (unsigned)(((((gy >> 1) * PW2 + (gx >> 1)) * (cin >> 5)) * 4 + (gy & 1) * 2 + (gx & 1)) * 4) : 0xFFFFFF00u;
+        return ok ? (((unsigned)((gy >> 1) * PW2 + (gx >> 1)) * (unsigned)(cin >> 5)) * 4u + (unsigned)((gy & 1) * 2 + (gx & 1))) * 4u : 0xFFFFFF00u;
     };
     auto b_ok = [&](int, int) -> bool { return true; };       // B_UNITS is a multiple of the workgroup size
     auto b_lds_of = [&](int i, int to) -> int { const int u = to + i * C::NT; return (u / QP) * ROWB + (u % QP) * 16; };
@@ -300,7 +300,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             // row window of the second source (a job evaluated on a stripe of a larger image adds the Gram backward on
             // the rows it owns only): rows outside read as zeros
             if (p.in2_rows > 0) ok = ok & ((unsigned)(gy - p.in2_row0) < (unsigned)p.in2_rows);
-            a_voff[i] = ok ? (unsigned)(((gy * p.W + gx) * cin + q * 4) * 4) : 0xFFFFFF00u;
+            a_voff[i] = ok ? ((unsigned)(gy * p.W + gx) * (unsigned)cin + (unsigned)q * 4u) * 4u : 0xFFFFFF00u;
             g_lds[i] = (py + 1) * C::PROWB + (px + 1) * ROWB + q * 8;
         }
 #pragma unroll
@@ -510,8 +510,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         const int wcolB = words * 4, wrowB = p.W * wcolB;            // the same for the bit-mask words
         const int pix0 = (y0 + wm * 4) * p.W + x0 + 4 * half;        // this lane's first pixel
         const int cg0 = n0 + wn * 32 * NTW;                          // this wave's first output channel
-        const unsigned vbase = (unsigned)(pix0 * colB + (cg0 + l31) * 4);
-        const unsigned wbase = (unsigned)(pix0 * wcolB + (cg0 >> 5) * 4);
+        const unsigned vbase = (unsigned)pix0 * (unsigned)colB + (unsigned)(cg0 + l31) * 4u;      // (mod 2^32: tensors up to 4 GiB)
+        const unsigned wbase = (unsigned)pix0 * (unsigned)wcolB + (unsigned)(cg0 >> 5) * 4u;
         const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
         // (mt, r) -> scalar offsets of the element's pixel: row (r >> 3) + 2 mt, column (r & 3) + 8 ((r >> 2) & 1)
         auto soff = [&](int mt, int r, int rb, int cb) { return ((r >> 3) + 2 * mt) * rb + ((r & 3) + 8 * ((r >> 2) & 1)) * cb; };
@@ -556,8 +556,8 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             // one lane per half-wave writes the bit words; the others carry an offset beyond the buffer (dropped)
             const unsigned wlane = (l31 == 0) ? wbase : 0xFFFFFF00u;
             const int ppix0 = ((y0 + wm * 4) >> 1) * PW2 + ((x0 + 4 * half) >> 1);
-            const unsigned pbase = (unsigned)(ppix0 * colB + (cg0 + l31) * 4);
-            const unsigned cbase = (l31 == 0) ? (unsigned)((ppix0 * words + (cg0 >> 5)) * 16) : 0xFFFFFF00u;
+            const unsigned pbase = (unsigned)ppix0 * (unsigned)colB + (unsigned)(cg0 + l31) * 4u;
+            const unsigned cbase = (l31 == 0) ? ((unsigned)ppix0 * (unsigned)words + (unsigned)(cg0 >> 5)) * 16u : 0xFFFFFF00u;
             const float lo_clamp = p.relu ? 0.f : -__builtin_inff();
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
