@@ -71,6 +71,8 @@ def mfma_roofline(mode, algorithmic_flops, ms, launches, extra=None):
            "achieved": hw, "peak": MFMA_PEAK[mode], "unit": "TFLOP/s", "frac": hw / MFMA_PEAK[mode],
            "algorithmic_tflops": alg, "mfma_work_factor": MFMA_WORK_FACTOR[mode],
            "frac_algorithmic_of_fp32_mfma_peak": alg / MFMA_PEAK["f32"],
+           # tools/micro/mfma_power.hip on this pool: MFMA-only kernel, random fp16 operands, 1 678 TFLOP/s (zeros: 2 461)
+           "frac_of_measured_random_data_mfma_ceiling": (hw / 1678.0) if mode != "f32" else None,
            "traffic": None, "launches": launches, "avg_launch_ms": ms / max(launches, 1),
            "flops_per_launch_avg": algorithmic_flops / max(launches, 1)}
     if extra:
