@@ -522,6 +522,44 @@ def test_errors_are_reported(eng, vgg_weights):
         eng.closure(torch.zeros(1, 3, 32, 48, device="cuda:0"), 1.0, 1.0, 1.0)
 
 
+def test_stripe_and_mode_errors_are_reported(vgg_weights, monkeypatch):
+    """Error behaviour of the newer entry points: misaligned stripes, a stripe context with several levels, missing
+    targets, the stripe closure outside the f16x2 mode, an unknown NST_CONV value."""
+    from artstyletransfer_amd._lib import NstError
+    from artstyletransfer_amd.engine import StyleEngine
+    e = StyleEngine(vgg_weights, 0)
+    try:
+        x = torch.zeros(1, 3, 64, 48, device="cuda:0")
+        e.configure(2, 64, 48)
+        with pytest.raises(NstError, match="levels_num = 1"):
+            e.window_begin(x, 0, 32, 128)
+        e.configure(1, 64, 48)
+        with pytest.raises(NstError, match="targets"):
+            e.window_begin(x, 0, 32, 128)
+        e.set_targets(0, x, x)
+        with pytest.raises(NstError, match="multiples of 16"):
+            e.window_begin(x, 8, 32, 128)           # start not on a 16-row boundary
+        with pytest.raises(NstError, match="multiples of 16"):
+            e.window_begin(x, 0, 24, 128)           # interior end not on a 16-row boundary
+        with pytest.raises(NstError, match="multiples of 16"):
+            e.window_begin(x, 32, 64, 128)          # beyond the stripe image
+        e.window_begin(x, 16, 48, 128)              # a bottom stripe may end on any row: fine
+    finally:
+        e.close()
+    monkeypatch.setenv("NST_CONV", "bf16x3")
+    e = StyleEngine(vgg_weights, 0)
+    try:
+        e.configure(1, 64, 48)
+        e.set_targets(0, x, x)
+        with pytest.raises(NstError, match="f16x2"):
+            e.window_begin(x, 0, 32, 128)
+    finally:
+        e.close()
+    monkeypatch.setenv("NST_CONV", "fp8")
+    with pytest.raises(NstError, match="NST_CONV"):
+        StyleEngine(vgg_weights, 0)
+
+
 # ---------------------------------------------------------------- job set-up on the device (rows f-1 / f-2)
 @pytest.mark.parametrize("h,w,nh,nw", [(20, 30, 40, 60), (64, 96, 32, 48), (37, 53, 256, 367), (256, 383, 9, 13), (9, 13, 256, 384)])
 def test_device_resize_vs_host(eng, h, w, nh, nw):
