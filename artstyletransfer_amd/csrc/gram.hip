@@ -387,7 +387,7 @@ int gram_nsplit(int C, size_t N) {
     const int T = C / ts;
     const int pairs = T * (T + 1) / 2;
     const size_t chunks = (N + kp - 1) / kp;
-    size_t ns = 512 / pairs;
+    size_t ns = 256 / pairs;          // (with 512 the partial slabs cost more HBM traffic than the maps themselves)
     const size_t by_bytes = ((size_t)32 << 20) / ((size_t)C * C * 4);
     if (ns > by_bytes) ns = by_bytes;
     if (ns > chunks) ns = chunks;
