@@ -193,7 +193,8 @@ int nst_ctx_bytes(const nst_ctx* ctx, size_t* bytes);
 
 /* wall time in ms of the kernels of the last nst_closure on `ctx`, measured with HIP events on
  * the streams the kernels ran on (0 if timing was not enabled with nst_set_timing). */
-int nst_set_timing(nst_ctx* ctx, int enabled);   /* 0 off, 1 whole closure, 2 + every kernel launch, 3 + only the 3x3 conv launches */
+int nst_set_timing(nst_ctx* ctx, int enabled);   /* 0 off, 1 whole closure, 2 + every kernel launch, 3 + only the 3x3 conv
+                                                    launches, 4 + those of every fourth closure only */
 int nst_last_closure_ms(nst_ctx* ctx, float* ms);
 /* last closure, per kernel class: summed launch durations (ms), launches, algorithmic flops.
  * cls: 0 = 3x3 MFMA convolutions (forward + input gradient), 1 = Gram forward + its 1x1 backward,
