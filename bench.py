@@ -71,8 +71,10 @@ def mfma_roofline(mode, algorithmic_flops, ms, launches, extra=None):
            "achieved": hw, "peak": MFMA_PEAK[mode], "unit": "TFLOP/s", "frac": hw / MFMA_PEAK[mode],
            "algorithmic_tflops": alg, "mfma_work_factor": MFMA_WORK_FACTOR[mode],
            "frac_algorithmic_of_fp32_mfma_peak": alg / MFMA_PEAK["f32"],
-           # tools/micro/mfma_power.hip on this pool: MFMA-only kernel, random fp16 operands, 1 678 TFLOP/s (zeros: 2 461)
-           "frac_of_measured_random_data_mfma_ceiling": (hw / 1678.0) if mode != "f32" else None,
+           # tools/micro/mfma_power.hip on this pool, random fp16 operands: MFMA-only kernel 1 680 TFLOP/s (zeros: 2 460),
+           # with the conv kernel's LDS fragment traffic 1 560
+           "frac_of_measured_random_data_mfma_ceiling": (hw / 1680.0) if mode != "f32" else None,
+           "frac_of_measured_mfma_plus_lds_ceiling": (hw / 1560.0) if mode == "f16x2" else None,
            "traffic": None, "launches": launches, "avg_launch_ms": ms / max(launches, 1),
            "flops_per_launch_avg": algorithmic_flops / max(launches, 1)}
     if extra:
