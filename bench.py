@@ -305,6 +305,9 @@ def main():
                        "job_setup_ms_on_device": round(getattr(cfg, "job_setup_ms", 0.0), 1)},
             "closure_tflops_algorithmic": closure_flops / 1e12,
             "closure_rate_tflops": closure_flops * (done / dt) / 1e12,
+            # whole-closure algorithmic rate over the fp32 matrix peak (the arithmetic the reference's
+            # torch path would need on this chip); > 1 because the products run as fp16 pieces on the 16-bit pipe
+            "closure_frac_of_fp32_mfma_peak": closure_flops * (done / dt) / 1e12 / MFMA_PEAK["f32"],
         }
         if not args.no_kernel_timing:
             ms, n, fl = eng.timing_totals(0)
