@@ -36,6 +36,8 @@ struct nst_opt {
     float* losses = nullptr;     // 4*levels+1
     double* scratch = nullptr;   // 2*RED_BLOCKS
     float* scal = nullptr;       // 4 floats
+    float* pinned = nullptr;     // page-locked host staging for the scalar read-backs (pageable targets make
+                                 // hipMemcpyAsync stage through an internal buffer: ~50 us per read-back)
     // adam
     float* m = nullptr; float* v = nullptr; int k = 0;
     // lbfgs
@@ -96,12 +98,14 @@ int eval_closure(nst_opt* o, const float* x, float cw, float sw, float tvw, hipS
     const size_t row = (size_t)NST_LOSS_ROW * o->levels + 1;
     const size_t off = o->loss_rows.size();
     o->loss_rows.resize(off + row);
-    OHIP(o, hipMemcpyAsync(o->loss_rows.data() + off, o->losses, row * sizeof(float), hipMemcpyDeviceToHost, s));
-    float r[3] = {0.f, 0.f, 0.f};
+    float* hrow = o->pinned + 8;                                             // [0..8): scalars, [8..): the loss row
+    OHIP(o, hipMemcpyAsync(hrow, o->losses, row * sizeof(float), hipMemcpyDeviceToHost, s));
+    float* r = o->pinned;
     if (gs && gs->want_abs) OHIP(o, launch_absmax_abssum(o->g, o->n, o->scratch, o->scal, s));
     if (gs && gs->dot_with) OHIP(o, launch_dot(o->g, gs->dot_with, o->n, o->scratch, o->scal + 2, s));
     if (gs) OHIP(o, hipMemcpyAsync(r, o->scal, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
     OHIP(o, hipStreamSynchronize(s));
+    std::memcpy(o->loss_rows.data() + off, hrow, row * sizeof(float));
     if (gs) { gs->gmax = r[0]; gs->gsum = r[1]; gs->gdot = r[2]; }
     o->total_closures += 1;                                                  // :198
     *loss_out = o->loss_rows[off + row - 1];
@@ -110,14 +114,15 @@ int eval_closure(nst_opt* o, const float* x, float cw, float sw, float tvw, hipS
 
 int dot(nst_opt* o, const float* a, const float* b, hipStream_t s, float* out) {
     OHIP(o, launch_dot(a, b, o->n, o->scratch, o->scal, s));
-    OHIP(o, hipMemcpyAsync(out, o->scal, sizeof(float), hipMemcpyDeviceToHost, s));
+    OHIP(o, hipMemcpyAsync(o->pinned, o->scal, sizeof(float), hipMemcpyDeviceToHost, s));
     OHIP(o, hipStreamSynchronize(s));
+    *out = o->pinned[0];
     return NST_OK;
 }
 // two dot products, one synchronisation
 int dot2(nst_opt* o, const float* a0, const float* b0, const float* a1, const float* b1, hipStream_t s, float* out0,
          float* out1) {
-    float r[2];
+    float* r = o->pinned;
     OHIP(o, launch_dot(a0, b0, o->n, o->scratch, o->scal, s));
     OHIP(o, launch_dot(a1, b1, o->n, o->scratch, o->scal + 1, s));
     OHIP(o, hipMemcpyAsync(r, o->scal, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -127,7 +132,7 @@ int dot2(nst_opt* o, const float* a0, const float* b0, const float* a1, const fl
 }
 // g . d together with max|d|, sum|d|, one synchronisation
 int dot_and_absstats(nst_opt* o, const float* g, const float* d, hipStream_t s, float* gtd, float* mx, float* sum) {
-    float r[3];
+    float* r = o->pinned;
     OHIP(o, launch_absmax_abssum(d, o->n, o->scratch, o->scal, s));
     OHIP(o, launch_dot(g, d, o->n, o->scratch, o->scal + 2, s));
     OHIP(o, hipMemcpyAsync(r, o->scal, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -136,7 +141,7 @@ int dot_and_absstats(nst_opt* o, const float* g, const float* d, hipStream_t s, 
     return NST_OK;
 }
 int absstats(nst_opt* o, const float* a, hipStream_t s, float* mx, float* sum) {
-    float r[2];
+    float* r = o->pinned;
     OHIP(o, launch_absmax_abssum(a, o->n, o->scratch, o->scal, s));
     OHIP(o, hipMemcpyAsync(r, o->scal, 2 * sizeof(float), hipMemcpyDeviceToHost, s));
     OHIP(o, hipStreamSynchronize(s));
@@ -347,6 +352,7 @@ int nst_opt_create(nst_ctx* ctx, int kind, float lr_start, int lbfgs_max_eval, n
     if (r == NST_OK) r = oalloc(o, &o->losses, (size_t)NST_LOSS_ROW * o->levels + 1);
     o->own_g = o->g; o->own_losses = o->losses;
     if (r == NST_OK) r = oalloc(o, &o->scal, 4);
+    if (r == NST_OK && hipHostMalloc(reinterpret_cast<void**>(&o->pinned), (8 + (size_t)NST_LOSS_ROW * NST_MAX_LEVELS + 1) * sizeof(float), hipHostMallocDefault) != hipSuccess) r = NST_E_NOMEM;
     if (r == NST_OK && hipMalloc(reinterpret_cast<void**>(&o->scratch), 2 * RED_BLOCKS * sizeof(double)) != hipSuccess) r = NST_E_NOMEM;
     if (r == NST_OK && kind == NST_OPT_ADAM) {
         r = oalloc(o, &o->m, o->n);
@@ -371,6 +377,7 @@ void nst_opt_destroy(nst_opt* o) {
     float* ptrs[] = {o->own_g, o->own_losses, o->scal, o->m, o->v, o->d, o->prev_g, o->xinit, o->q};
     for (float* p : ptrs) if (p) (void)hipFree(p);
     if (o->scratch) (void)hipFree(o->scratch);
+    if (o->pinned) (void)hipHostFree(o->pinned);
     for (float* p : o->old_dirs) (void)hipFree(p);
     for (float* p : o->old_stps) (void)hipFree(p);
     for (float* p : o->spare) (void)hipFree(p);
