@@ -325,7 +325,7 @@ int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s
     for (int l = 0; l < NL; ++l) a.bits_valid[l] = false;
     for (int k = 0; k < 4; ++k) a.pooled[k] = false;
     const bool h2 = ctx->conv_mode == 2;
-    if (h2) HIPCHK(ctx, hipMemsetAsync(a.amax, 0, (size_t)(NL + 5) * NST_AMAX_SLOTS * 4, s));     // act + S records
+    if (h2) HIPCHK(ctx, launch_zero(a.amax, (size_t)(NL + 5) * NST_AMAX_SLOTS, s));     // act + S records
     {
         Timer t(ctx, s, K_CONV1, conv_flops(h, w, 3, 64, 9));
         unsigned* bits = ctx->conv_mode ? a.bits[0] : nullptr;
@@ -385,7 +385,7 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
     float* cur = gbuf0;     // holds the gradient w.r.t. the pre-ReLU output of the layer being processed
     float* oth = gbuf1;
     const bool h2 = ctx->conv_mode == 2;
-    if (h2) HIPCHK(ctx, hipMemsetAsync(amax_grad(a, 0), 0, (size_t)NL * NST_AMAX_SLOTS * 4, s));
+    if (h2) HIPCHK(ctx, launch_zero(amax_grad(a, 0), (size_t)NL * NST_AMAX_SLOTS, s));
     // top: layer 12
     {
         const int l = NL - 1;
@@ -400,7 +400,7 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
             Timer t(ctx, s, K_OTHER, 0);
             HIPCHK(ctx, launch_relu_mask(a.act[l], inj[l].direct, n, cur, s));
         } else {
-            HIPCHK(ctx, hipMemsetAsync(cur, 0, n * 4, s));
+            HIPCHK(ctx, launch_zero(cur, n, s));
         }
         if (h2) HIPCHK(ctx, launch_absmax_slots(cur, n, amax_grad(a, l), s));
     }
@@ -523,7 +523,7 @@ int batched_forward(nst_ctx* ctx, const float* const* xi, const int* lv, int n, 
         ActSet& a = L.acts;
         for (int l = 0; l < NL; ++l) a.bits_valid[l] = false;
         for (int q = 0; q < 4; ++q) a.pooled[q] = false;
-        if (h2) HIPCHK(ctx, hipMemsetAsync(a.amax, 0, (size_t)AMAX_IDS * NST_AMAX_SLOTS * 4, s));
+        if (h2) HIPCHK(ctx, launch_zero(a.amax, (size_t)AMAX_IDS * NST_AMAX_SLOTS, s));
         {
             Timer t(ctx, s, K_OTHER, 0);
             HIPCHK(ctx, launch_tv_partial(xi[lv[k]], 3, L.h, L.w, L.tv_partial, s, win ? win->row0 : 0, win ? win->rows : 0));
@@ -672,7 +672,7 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
                     const size_t off = (size_t)win_r0(*win, kScale[m]) * a.w[m] * kCout[m];
                     const size_t cnt = (size_t)win_nr(*win, kScale[m]) * a.w[m] * kCout[m];
                     const double n_all = (double)(win->H0 >> kScale[m]) * a.w[m] * kCout[m];
-                    HIPCHK(ctx, hipMemsetAsync(oth[k], 0, L.content_n * sizeof(float), s));
+                    HIPCHK(ctx, launch_zero(oth[k], L.content_n, s));
                     HIPCHK(ctx, launch_mse_grad(a.act[m] + off, L.content_t + off, cnt, (float)((double)cw * 2.0 / n_all),
                                                 oth[k] + off, L.content_partial, s));
                 } else {
@@ -718,7 +718,7 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
     int lv[NST_MAX_LEVELS], n = 0;
     for (int i = 0; i < ctx->levels; ++i) {
         if ((level_mask >> i) & 1u) lv[n++] = i;
-        else HIPCHK(ctx, hipMemsetAsync(gi[i], 0, (size_t)3 * ctx->lv[i].h * ctx->lv[i].w * sizeof(float), s));
+        else HIPCHK(ctx, launch_zero(gi[i], (size_t)3 * ctx->lv[i].h * ctx->lv[i].w, s));
     }
     if (n == 0) return NST_OK;
     NSTCHK(batched_forward(ctx, xi, lv, n, s, nullptr));
@@ -1025,8 +1025,11 @@ int nst_closure_levels(nst_ctx* ctx, const float* x, float cw, float sw, float t
     ctx->sample_now = (ctx->timing != 4) || ((ctx->closure_seq++ & 3) == 0);
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->t0, main));
 
-    // Optional (NST_GRAPH=1): replay the ~110 dependent launches as a hipGraph.  Captured the second consecutive time the same buffers / weights / mask are passed (optimiser
-    // drivers always pass the same ones), never while per-launch timing is on.
+    // Optional (NST_GRAPH=1): replay the ~110 dependent launches as a hipGraph.  Captured the second consecutive time the
+    // same buffers / weights / mask are passed (optimiser drivers always pass the same ones), never while per-launch
+    // timing is on.  The closure holds kernel nodes only: hipMemsetAsync nodes were NOT ordered against the kernels
+    // around them on replay (absmax records zeroed late -> garbage scales, run-to-run different losses), which is why
+    // every zero fill in the closure is launch_zero.  Measured gain: none (the host runs ~16 ms ahead of the GPU).
     const nst_ctx::GraphKey key{x, grad, losses, cw, sw, tvw, level_mask};
     const bool same_as_last = std::memcmp(&key, &ctx->glast, sizeof(key)) == 0;
     ctx->glast = key;
@@ -1079,7 +1082,7 @@ static int closure_record(nst_ctx* ctx, const float* x, float cw, float sw, floa
         if (multi) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->fork, 0));
         if (!((level_mask >> i) & 1u)) {
             // a level another rank owns: it contributes nothing here (its gradient arrives by all-reduce)
-            HIPCHK(ctx, hipMemsetAsync(gi[i], 0, (size_t)3 * L.h * L.w * sizeof(float), s));
+            HIPCHK(ctx, launch_zero(gi[i], (size_t)3 * L.h * L.w, s));
             if (multi) HIPCHK(ctx, hipEventRecord(L.done, s));
             continue;
         }
@@ -1349,7 +1352,7 @@ int nst_gram(nst_ctx* ctx, const float* f, int C, int h, int w, int normalize, f
     if (r == NST_OK && launch_chw_to_hwc(f, C, h, w, nhwc, s) != hipSuccess) r = fail(ctx, NST_E_HIP, "chw_to_hwc launch failed");
     if (r == NST_OK && amax) {
         // the fp16-piece kernel needs the absmax of its operand (in the closure the producing conv records it)
-        if (hipMemsetAsync(amax, 0, NST_AMAX_SLOTS * 4, s) != hipSuccess || launch_absmax_slots(nhwc, N * C, amax, s) != hipSuccess)
+        if (launch_zero(amax, NST_AMAX_SLOTS, s) != hipSuccess || launch_absmax_slots(nhwc, N * C, amax, s) != hipSuccess)
             r = fail(ctx, NST_E_HIP, "absmax launch failed");
     }
     if (r == NST_OK)

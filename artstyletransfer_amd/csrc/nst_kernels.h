@@ -230,6 +230,7 @@ hipError_t launch_axpy(float alpha, const float* x, float* y, size_t n, hipStrea
 hipError_t launch_axpy_dev(const float* alpha_dev, float sign, const float* x, float* y, size_t n, hipStream_t stream);
 hipError_t launch_scale_copy(float alpha, const float* x, float* y, size_t n, hipStream_t stream);         // y = alpha*x
 hipError_t launch_add_scaled(const float* a, float alpha, const float* b, float* out, size_t n, hipStream_t stream);  // out = a + alpha*b
+hipError_t launch_zero(void* out, size_t n_words, hipStream_t stream);                                      // out[0..n) = 0 (32-bit words, 16-byte aligned)
 hipError_t launch_copy(const float* a, float* out, size_t n, hipStream_t stream);                          // out = a (16-byte aligned)
 hipError_t launch_sub(const float* a, const float* b, float* out, size_t n, hipStream_t stream);           // out = a-b
 hipError_t launch_adam(float* x, const float* g, float* m, float* v, size_t n, float beta1, float beta2, float eps,

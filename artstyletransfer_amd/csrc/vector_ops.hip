@@ -139,6 +139,19 @@ __global__ void copy_kernel(const float* __restrict__ a, float* __restrict__ out
         reinterpret_cast<f32x4v*>(out)[i] = reinterpret_cast<const f32x4v*>(a)[i];
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = a[n4 * 4 + threadIdx.x];
 }
+// zero fill (n 32-bit words, 16-byte aligned base): a kernel, not hipMemsetAsync - the memset nodes of a captured closure
+// were not reliably ordered against the kernels around them in a hipGraph replay, and a kernel is no slower eagerly
+__global__ void zero_kernel(float* __restrict__ out, size_t n) {
+    const size_t n4 = n / 4;
+    const f32x4v z = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4v*>(out)[i] = z;
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) out[n4 * 4 + threadIdx.x] = 0.f;
+}
+hipError_t launch_zero(void* out, size_t n_words, hipStream_t stream) {
+    hipLaunchKernelGGL(zero_kernel, dim3(vblocks(n_words / 4 + 1)), dim3(256), 0, stream, static_cast<float*>(out), n_words);
+    return hipGetLastError();
+}
 hipError_t launch_add_scaled(const float* a, float alpha, const float* b, float* out, size_t n, hipStream_t stream) {
     hipLaunchKernelGGL(add_scaled_kernel, dim3(vblocks(n / 4 + 1)), dim3(256), 0, stream, a, alpha, b, out, n);
     return hipGetLastError();
