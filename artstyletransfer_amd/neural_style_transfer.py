@@ -110,25 +110,34 @@ class NeuralStyleTransfer:
         dev = self.__device
         h0, w0 = init_img.shape[:2]
         engine = StyleEngine(load_weights(), dev)
+        # Every job runs on a HIP stream of its own: the jobs that share a GPU (`config.simultaneous_tasks_count`
+        # per GPU, as in the reference) then overlap on the device - one job's launch tails, host round trips and
+        # HBM-bound kernels run under the other's MFMA-bound ones - instead of queueing behind each other on the
+        # default stream.  The current stream is per THREAD and the jobs' coroutines share the event-loop thread, so
+        # it is set around synchronous sections only, never across an await.
+        job_stream = torch.cuda.Stream(device=dev)
+        job_stream.wait_stream(torch.cuda.current_stream(dev))     # the caller built the input images there
         try:
-            engine.configure(len(content_imgs), h0, w0)
             def prepared(img):      # numpy HWC (reference) or a device HWC tensor built by device_image
                 if isinstance(img, torch.Tensor):
                     return engine.prepare_img(img.to(dev).contiguous())
                 return prepare_img(img, dev)
 
-            for lvl, (c_img, s_img) in enumerate(zip(content_imgs, self.__style_imgs)):
-                if tuple(c_img.shape[:2]) != engine.level_shape(lvl):
-                    raise ValueError(f"content level {lvl} is {tuple(c_img.shape[:2])}, expected {engine.level_shape(lvl)}")
-                engine.set_targets(lvl, prepared(c_img), prepared(s_img))
-            optimizing_img = prepared(init_img)
-            optimizer = PixelOptimizer(engine, self.__optimizer_name, lr_start, LBFGS_MAX_EVAL)
+            with torch.cuda.stream(job_stream):
+                engine.configure(len(content_imgs), h0, w0)
+                for lvl, (c_img, s_img) in enumerate(zip(content_imgs, self.__style_imgs)):
+                    if tuple(c_img.shape[:2]) != engine.level_shape(lvl):
+                        raise ValueError(f"content level {lvl} is {tuple(c_img.shape[:2])}, expected {engine.level_shape(lvl)}")
+                    engine.set_targets(lvl, prepared(c_img), prepared(s_img))
+                optimizing_img = prepared(init_img)
+                optimizer = PixelOptimizer(engine, self.__optimizer_name, lr_start, LBFGS_MAX_EVAL)
             cw, sw, tvw = float(content_weight), float(style_weight), float(tv_weight)
             step = 0
 
             def one_step():
                 try:
-                    return optimizer.step(optimizing_img, cw, sw, tvw, want_losses=True)
+                    with torch.cuda.stream(job_stream):         # a pool thread: its current stream is its own
+                        return optimizer.step(optimizing_img, cw, sw, tvw, want_losses=True)
                 except Exception:
                     traceback.print_exc()
                     raise
@@ -149,7 +158,7 @@ class NeuralStyleTransfer:
                     if VERBOSE:
                         for r in rows:
                             print(f"{self.__optimizer_name} | {init_img_name} | lr={info.lr:.4f} | total loss={r[-1]:.3e}")
-                    with torch.cuda.device(dev):
+                    with torch.cuda.device(dev), torch.cuda.stream(job_stream):
                         snap = engine.unprepare_img(optimizing_img)      # ordered before the next step on the stream
                         ready = torch.cuda.Event()
                         ready.record()
@@ -173,6 +182,7 @@ class NeuralStyleTransfer:
                         pass
             optimizer.close()
         finally:
+            job_stream.synchronize()
             engine.close()
 
 
