@@ -507,9 +507,11 @@ def test_level_sharded_closure_adds_up(eng, vgg_weights):
     assert float(parts[1][1][0]) == 0.0 and float(parts[0][1][4]) == 0.0      # rows of foreign levels are zeros
 
 
-def test_full_size_job_properties(monkeypatch):
+@pytest.mark.parametrize("levels_num", [3, 5])
+def test_full_size_job_properties(monkeypatch, levels_num):
     """BASELINE config 3 (L=2: 1024x1536 top level, three levels, noise init) at full size, where the oracle takes
-    minutes per closure: size-independent properties instead.  (1) the closure is idempotent - bitwise the same
+    minutes per closure, and the largest job tried (L=4: 4096x6144, five levels, ~45 GB of activations, level-0
+    tensors beyond 4 GiB that take the 64-bit-addressed code paths): size-independent properties instead.  (1) the closure is idempotent - bitwise the same
     gradient and loss rows when evaluated twice; (2) it is additive over levels - disjoint level subsets sum to
     the full closure; (3) each level's row obeys total = cw*content + sw*style + tvw*tv and the grand total is the
     sum of the level totals; (4) the independent exact-f32-MFMA arithmetic on the per-level schedule gives the
@@ -518,23 +520,27 @@ def test_full_size_job_properties(monkeypatch):
     import bench
     from artstyletransfer_amd import sharding
     monkeypatch.delenv("NST_CONV", raising=False)
-    eng, x, cfg, _ = bench.build_job(3, 0, 0)
+    n = levels_num
+    eng, x, cfg, _ = bench.build_job(n, 0, 0)
     cw, sw, tvw = cfg.content_weight, cfg.style_weight, cfg.tv_weight
     try:
-        assert tuple(x.shape) == (1, 3, 1024, 1536)
+        assert tuple(x.shape) == (1, 3, 256 << (n - 1), 384 << (n - 1))
         g0, l0 = eng.closure(x, cw, sw, tvw)
         g0, l0 = g0.clone(), l0.clone()
         g1, l1 = eng.closure(x, cw, sw, tvw)
         assert torch.equal(g0, g1) and torch.equal(l0, l1)
         assert bool(torch.isfinite(g0).all()) and bool(torch.isfinite(l0).all())
-        rows = l0[:-1].double().cpu().numpy().reshape(3, 4)
+        rows = l0[:-1].double().cpu().numpy().reshape(n, 4)
         np.testing.assert_allclose(rows[:, 0], cw * rows[:, 1] + sw * rows[:, 2] + tvw * rows[:, 3], rtol=2e-6)
         np.testing.assert_allclose(float(l0[-1]), rows[:, 0].sum(), rtol=1e-6)
-        parts = [eng.closure_levels(x, cw, sw, tvw, sharding.level_mask(3, r, 3)) for r in range(3)]
-        parts = [(g.clone(), l.clone()) for g, l in parts]
-        g_sum = (parts[0][0].double() + parts[1][0].double() + parts[2][0].double())
+        g_sum, l_sum = torch.zeros_like(g0, dtype=torch.float64), torch.zeros_like(l0)
+        for r in range(n):
+            g, l = eng.closure_levels(x, cw, sw, tvw, sharding.level_mask(n, r, n))
+            g_sum += g.double()
+            l_sum += l
         assert float((g_sum - g0.double()).norm() / g0.double().norm()) < 1e-6
-        np.testing.assert_allclose((parts[0][1] + parts[1][1] + parts[2][1]).cpu().numpy(), l0.cpu().numpy(), rtol=1e-6)
+        np.testing.assert_allclose(l_sum.cpu().numpy(), l0.cpu().numpy(), rtol=1e-6)
+        del g_sum
         # directional derivative
         d = g0 / g0.abs().max()
         eps = 0.25
@@ -546,7 +552,7 @@ def test_full_size_job_properties(monkeypatch):
         eng.close()
     monkeypatch.setenv("NST_CONV", "f32")
     monkeypatch.setenv("NST_BATCH", "0")
-    other, x2, _, _ = bench.build_job(3, 0, 0)
+    other, x2, _, _ = bench.build_job(n, 0, 0)
     try:
         assert other.conv_mode() == "f32" and torch.equal(x2, x)
         g2, l2 = other.closure(x2, cw, sw, tvw)
