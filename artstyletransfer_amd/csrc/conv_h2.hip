@@ -129,8 +129,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     const int half = lane >> 5;
     const int l31 = lane & 31;
 
-    const int ty = sp / p.tiles_x;
-    const int tx = sp - ty * p.tiles_x;
+    const int ty_rel = sp / p.tiles_x;
+    const int tx = sp - ty_rel * p.tiles_x;
+    const int ty = ty_rel + p.ty0;
     const int y0 = ty * TH;
     const int x0 = tx * C::TW;
     const int n0 = ct * BN;
@@ -711,7 +712,7 @@ __global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_batch
     p.wt_h2 = b.wt_h2; p.wt_h2_inv = b.wt_h2_inv; p.wt2_f32 = im.wt2_f32;
     p.amax_in = im.amax_in; p.amax_in2 = im.amax_in2; p.amax_w2 = im.amax_w2; p.amax_out = im.amax_out;
     p.pcode_in = im.pcode_in; p.pcode_out = im.pcode_out;
-    p.in2_row0 = im.in2_row0; p.in2_rows = im.in2_rows;
+    p.in2_row0 = im.in2_row0; p.in2_rows = im.in2_rows; p.ty0 = 0;
     conv_h2_body<TH, BN, NTW, KC, UNPOOL>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), blockIdx.x % n_ct, blockIdx.x);
 }
 
@@ -799,8 +800,6 @@ hipError_t launch_conv_h2_batch(const ConvBatch& b0, hipStream_t stream) {
 hipError_t launch_conv_h2(const ConvParams& p0, hipStream_t stream) {
     if (!h2_operands_ok(p0.wt_h2, p0.amax_in, p0.Cin, p0.Cout, p0.in2, p0.wt2_f32, p0.amax_in2, p0.amax_w2, p0.Cin2))
         return hipErrorInvalidValue;
-    // 32-bit buffer offsets: the input tensor must stay below 4 GiB (callers fall back to conv_mfma.hip beyond)
-    if ((size_t)p0.H * p0.W * (p0.Cin > p0.Cin2 ? p0.Cin : p0.Cin2) * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
     ConvParams p = p0;
     p.ksplit = 1;
     const bool wide = (p.Cout % 128 == 0);
@@ -808,13 +807,46 @@ hipError_t launch_conv_h2(const ConvParams& p0, hipStream_t stream) {
     const bool shortk = wide && p.Cin > 0 && p.Cin <= NST_H2_SHORTK_CIN;
     const int th = shortk ? 8 : h2_tile_rows(p.Cout, blocks16), bn = wide ? 128 : 64;
     p.tiles_x = (p.W + 15) / 16;
-    p.tiles_y = (p.H + th - 1) / th;
-    const int blocks = p.tiles_x * p.tiles_y * (p.Cout / bn);
-    if (!wide) launch_single_cfg<16, 64, 2, 16>(p, blocks, stream);
-    else if (shortk) launch_single_cfg<8, 128, 2, 16>(p, blocks, stream);
-    else if (th == 8) launch_single_cfg<8, 128, 1, 32>(p, blocks, stream);
-    else launch_single_cfg<16, 128, 2, 32>(p, blocks, stream);
-    return hipGetLastError();
+    // The kernels address with 32-bit buffer offsets.  A launch whose tensors reach 4 GiB runs in bands of output rows
+    // (multiples of 16, so tiles and pooling windows stay aligned): every tensor pointer is moved to the band's first
+    // row minus a 16-row halo, the band "image" ends 16 rows below the band, and only the band's tile rows are
+    // launched - the halo rows are read, never written.
+    const int cmax = p.Cin > p.Cout ? (p.Cin > p.Cin2 ? p.Cin : p.Cin2) : (p.Cout > p.Cin2 ? p.Cout : p.Cin2);
+    const size_t row_bytes = (size_t)p.W * cmax * 4;
+    int band_rows = p.H;
+    if ((size_t)p.H * row_bytes >= 0xFFFFFF00ull) {
+        const long fit = (long)(0xFFFFFF00ull / row_bytes) - 32;
+        band_rows = (int)(fit / 16) * 16;
+        if (band_rows < 16) return hipErrorInvalidValue;
+    }
+    const int PW2 = p.W >> 1, wi = p.Cin >> 5, wo = p.Cout >> 5;
+    for (int r0 = 0; r0 < p.H; r0 += band_rows) {
+        const int r1 = (r0 + band_rows < p.H) ? r0 + band_rows : p.H;
+        const int b0 = (r0 >= 16) ? r0 - 16 : 0, b1 = (r1 + 16 < p.H) ? r1 + 16 : p.H;
+        ConvParams q = p;
+        const size_t px0 = (size_t)b0 * p.W, pp0 = (size_t)(b0 >> 1) * PW2;       // first pixel / pooled pixel of the band image
+        if (q.pcode_in) { q.in += pp0 * p.Cin; q.pcode_in += pp0 * wi * 4; }
+        else if (q.in) q.in += px0 * p.Cin;
+        if (q.in2) { q.in2 += px0 * p.Cin2; if (q.in2_rows > 0) q.in2_row0 -= b0; }
+        q.out += px0 * p.Cout;
+        if (q.addend) q.addend += px0 * p.Cout;
+        if (q.mask) q.mask += px0 * p.Cout;
+        if (q.bits_in) q.bits_in += px0 * wo;
+        if (q.bits_out) q.bits_out += px0 * wo;
+        if (q.pool_out) q.pool_out += pp0 * p.Cout;
+        if (q.pcode_out) q.pcode_out += pp0 * wo * 4;
+        q.H = b1 - b0;
+        q.ty0 = (r0 - b0) / th;
+        q.tiles_y = (r1 - r0 + th - 1) / th;
+        const int blocks = q.tiles_x * q.tiles_y * (p.Cout / bn);
+        if (!wide) launch_single_cfg<16, 64, 2, 16>(q, blocks, stream);
+        else if (shortk) launch_single_cfg<8, 128, 2, 16>(q, blocks, stream);
+        else if (th == 8) launch_single_cfg<8, 128, 1, 32>(q, blocks, stream);
+        else launch_single_cfg<16, 128, 2, 32>(q, blocks, stream);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 // ---- absmax of a tensor into its 64 slots (producers without an epilogue of their own) -----------------------

@@ -211,12 +211,13 @@ __device__ __forceinline__ void gram_h2_body(const float* __restrict__ f, size_t
         inv = __uint_as_float((unsigned)(e - 14) << 23);
     }
 
-    // pixels beyond p1 read as zeros (buffer range check)
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(f), 0,
-                                                                          (unsigned)(p1 * (size_t)C * 4), 0x00020000);
+    // pixels beyond p1 read as zeros (buffer range check).  The descriptor starts at this split's first pixel, so the
+    // 32-bit offsets span one split only and the map itself may exceed 4 GiB.
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(f) + p0 * (size_t)C, 0, (p0 < p1) ? (unsigned)((p1 - p0) * (size_t)C * 4) : 0u, 0x00020000);
     float st[G::SIDES][G::PER_T][8];
     auto load = [&](int chunk) {
-        const unsigned base = (unsigned)((p0 + (size_t)chunk * G::KP) * (size_t)C * 4);
+        const unsigned base = (unsigned)((size_t)chunk * G::KP * (size_t)C * 4);
 #pragma unroll
         for (int sd = 0; sd < G::SIDES; ++sd) {
             if (sd == 1 && diag) break;
@@ -421,8 +422,6 @@ hipError_t gram_init_device() {
 hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, const unsigned* amax, float* part,
                                hipStream_t stream) {
     const int ts = gram_ts(C);
-    // fp16-piece kernel when the absmax record of f is available (32-bit buffer offsets: tensor below 4 GiB)
-    const bool h2 = amax != nullptr && ts != 0 && N * (size_t)C * 4 < 0xFFFFFF00ull;
     if (ts == 0) {
         hipLaunchKernelGGL(gram_generic_kernel, dim3(C * C), dim3(256), 0, stream, f, N, C, part);
         return hipGetLastError();
@@ -433,6 +432,8 @@ hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, cons
     const size_t chunks = (N + kp - 1) / kp;
     const size_t cps = (chunks + nsplit - 1) / nsplit;
     const size_t pix_per_split = cps * kp;
+    // fp16-piece kernel when the absmax record of f is available (32-bit buffer offsets inside one split)
+    const bool h2 = amax != nullptr && pix_per_split * (size_t)C * 4 < 0xFFFFFF00ull;
     if (h2 && ts == 128) {
         hipLaunchKernelGGL(gram_h2_kernel<128>, dim3(pairs * nsplit), dim3(256), GramH2Cfg<128>::LDS_BYTES, stream, f, N, C,
                            nsplit, pix_per_split, amax, part);
@@ -568,7 +569,7 @@ hipError_t launch_gram_batch(const GramBatch& b0, hipStream_t stream) {
         for (int i = 0; i < b0.n; ++i) {
             const GramItem& src = b0.it[i];
             if (gram_ts(src.C) != ts) continue;
-            if (!src.amax || src.N * (size_t)src.C * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
+            if (!src.amax) return hipErrorInvalidValue;
             GramItem& it = b.it[b.n];
             it = src;
             const int kp = (ts == 128) ? 32 : 128;
@@ -576,6 +577,8 @@ hipError_t launch_gram_batch(const GramBatch& b0, hipStream_t stream) {
             const size_t chunks = (it.N + kp - 1) / kp;
             it.nsplit = gram_nsplit(it.C, it.N);
             it.pix_per_split = ((chunks + it.nsplit - 1) / it.nsplit) * kp;
+            // 32-bit buffer offsets inside ONE split (the map itself may be larger)
+            if (it.pix_per_split * (size_t)it.C * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
             it.part_end = (b.n ? b.it[b.n - 1].part_end : 0) + pairs * it.nsplit;
             ++b.n;
         }

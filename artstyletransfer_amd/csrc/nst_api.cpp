@@ -299,8 +299,9 @@ struct Timer {
 
 double conv_flops(int h, int w, int cin, int cout, int taps) { return 2.0 * h * w * (double)cin * cout * taps; }
 
-// the 16-bit-piece kernels address with 32-bit buffer offsets: tensors from 4 GiB up go to the fp32 kernel
+// the bf16-piece kernels address with 32-bit buffer offsets: tensors from 4 GiB up go to the fp32 kernel
 bool uses_pieces(const nst_ctx* ctx, const ConvParams& p) {
+    if (ctx->conv_mode == 2) return true;           // launch_conv_h2 runs larger tensors in row bands
     return ctx->conv_mode != 0 && (size_t)p.H * p.W * p.Cin * 4 < 0xFFFFFF00ull;
 }
 // 3x3 conv dispatch by mode; whatever kernel runs, the absmax record of the output is produced when asked for

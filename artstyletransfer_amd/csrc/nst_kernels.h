@@ -44,6 +44,7 @@ struct ConvParams {
     const unsigned* pcode_in;
     unsigned* pcode_out;
     int in2_row0, in2_rows;    // in2_rows > 0: the second source contributes on output rows [in2_row0, in2_row0 + in2_rows) only
+    int ty0;                   // first tile row of this launch (filled by the launcher: tensors from 4 GiB up run in row bands)
 };
 
 constexpr int NST_AMAX_SLOTS = 64;
