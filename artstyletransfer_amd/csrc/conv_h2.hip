@@ -689,17 +689,33 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     record_amax();
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every XCD has its own L2.  The
+// logical tile index is therefore re-dealt so that each XCD works through ONE contiguous range of tiles: the
+// output-channel tiles of a spatial tile (same input patch) and its neighbours (shared halo) then meet in one L2
+// instead of fetching the patch from HBM once per XCD.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_contiguous(const int b, const int grid) {
+#ifdef NST_NO_XCD_MAP
+    return b;
+#else
+    const int x = b & 7, k = b >> 3;
+    const int q = grid >> 3, r = grid & 7;
+    return x * q + (x < r ? x : r) + k;
+#endif
+}
+
 template <int TH, int BN, int NTW, int KC, bool UNPOOL>
 __global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_kernel(ConvParams p) {
     const int n_ct = p.Cout / BN;
-    conv_h2_body<TH, BN, NTW, KC, UNPOOL>(p, blockIdx.x / n_ct, blockIdx.x % n_ct, blockIdx.x);
+    const int t = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    conv_h2_body<TH, BN, NTW, KC, UNPOOL>(p, t / n_ct, t % n_ct, blockIdx.x);
 }
 
 // One launch = one layer over several images (the pyramid levels of a closure), see conv_bf3.hip.
 template <int TH, int BN, int NTW, int KC, bool UNPOOL>
 __global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_batch_kernel(ConvBatch b) {
     const int n_ct = b.Cout / BN;
-    const int sp_all = blockIdx.x / n_ct;
+    const int t = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+    const int sp_all = t / n_ct;
     int i = 0;
     while (i + 1 < b.n && sp_all >= b.img[i].tile_end) ++i;
     const ConvImage& im = b.img[i];
@@ -713,7 +729,7 @@ __global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_batch
     p.amax_in = im.amax_in; p.amax_in2 = im.amax_in2; p.amax_w2 = im.amax_w2; p.amax_out = im.amax_out;
     p.pcode_in = im.pcode_in; p.pcode_out = im.pcode_out;
     p.in2_row0 = im.in2_row0; p.in2_rows = im.in2_rows; p.ty0 = 0;
-    conv_h2_body<TH, BN, NTW, KC, UNPOOL>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), blockIdx.x % n_ct, blockIdx.x);
+    conv_h2_body<TH, BN, NTW, KC, UNPOOL>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), t % n_ct, blockIdx.x);
 }
 
 template <int TH, int BN, int NTW, int KC, bool UNPOOL>
