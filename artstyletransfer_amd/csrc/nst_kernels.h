@@ -227,6 +227,10 @@ hipError_t launch_dot(const float* a, const float* b, size_t n, double* scratch,
 // out[0] = max|a|, out[1] = sum|a|
 hipError_t launch_absmax_abssum(const float* a, size_t n, double* scratch, float* out, hipStream_t stream);
 // y = alpha * x + beta * y'  variants
+hipError_t launch_dot_partial(const float* a, const float* b, size_t n, double* scratch, hipStream_t stream);   // RED_BLOCKS partials
+// one history pair of the L-BFGS two-loop recursion on the device (see vector_ops.hip)
+hipError_t launch_lbfgs_pair(const double* sin, float ro, float* al, int second, const float* x, float* y, const float* nxt,
+                             size_t n, double* sout, hipStream_t stream);
 hipError_t launch_axpy(float alpha, const float* x, float* y, size_t n, hipStream_t stream);               // y += alpha*x
 hipError_t launch_axpy_dev(const float* alpha_dev, float sign, const float* x, float* y, size_t n, hipStream_t stream);
 hipError_t launch_scale_copy(float alpha, const float* x, float* y, size_t n, hipStream_t stream);         // y = alpha*x

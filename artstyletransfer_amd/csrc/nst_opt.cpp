@@ -36,6 +36,7 @@ struct nst_opt {
     float* losses = nullptr;     // 4*levels+1
     double* scratch = nullptr;   // 2*RED_BLOCKS
     float* scal = nullptr;       // 4 floats
+    float* al_dev = nullptr;     // L-BFGS: the al_i of the two-loop recursion, one per history pair
     float* pinned = nullptr;     // page-locked host staging for the scalar read-backs (pageable targets make
                                  // hipMemcpyAsync stage through an internal buffer: ~50 us per read-back)
     // adam
@@ -290,21 +291,27 @@ int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t 
         } else {
             o->spare.push_back(y); o->spare.push_back(st);
         }
+        // two-loop recursion (lbfgs.py:444-460) without a host round trip per pair: every launch finishes the previous
+        // launch's dot product, applies its pair's update and leaves the partials of the next pair's dot product
+        // (vector_ops.hip::lbfgs_pair_kernel).  The two halves of `scratch` alternate as the partials buffer.
         const int num_old = (int)o->old_dirs.size();
-        std::vector<float> al(num_old);
+        double* pp[2] = {o->scratch, o->scratch + RED_BLOCKS};
+        int cur = 0;
         OHIP(o, launch_scale_copy(-1.f, o->g, o->q, o->n, s));   // q = -g
+        if (num_old > 0) OHIP(o, launch_dot_partial(o->old_stps[num_old - 1], o->q, o->n, pp[cur], s));
         for (int i = num_old - 1; i >= 0; --i) {
-            float sq;
-            OCHK(dot(o, o->old_stps[i], o->q, s, &sq));
-            al[i] = sq * o->ro[i];
-            OHIP(o, launch_axpy(-al[i], o->old_dirs[i], o->q, o->n, s));
+            // al_i = (s_i . q) ro_i ;  q -= al_i y_i ;  partials of s_{i-1} . q
+            OHIP(o, launch_lbfgs_pair(pp[cur], o->ro[i], o->al_dev + i, 0, o->old_dirs[i], o->q,
+                                      i > 0 ? o->old_stps[i - 1] : nullptr, o->n, pp[cur ^ 1], s));
+            cur ^= 1;
         }
         OHIP(o, launch_scale_copy(o->H_is_one ? 1.f : o->H_diag, o->q, o->d, o->n, s));   // d = r = q * H_diag
+        if (num_old > 0) OHIP(o, launch_dot_partial(o->old_dirs[0], o->d, o->n, pp[cur], s));
         for (int i = 0; i < num_old; ++i) {
-            float yr;
-            OCHK(dot(o, o->old_dirs[i], o->d, s, &yr));
-            const float be = yr * o->ro[i];
-            OHIP(o, launch_axpy(al[i] - be, o->old_stps[i], o->d, o->n, s));
+            // be_i = (y_i . r) ro_i ;  r += (al_i - be_i) s_i ;  partials of y_{i+1} . r
+            OHIP(o, launch_lbfgs_pair(pp[cur], o->ro[i], o->al_dev + i, 1, o->old_stps[i], o->d,
+                                      i + 1 < num_old ? o->old_dirs[i + 1] : nullptr, o->n, pp[cur ^ 1], s));
+            cur ^= 1;
         }
     }
     OHIP(o, launch_copy(o->g, o->prev_g, o->n, s));
@@ -352,6 +359,7 @@ int nst_opt_create(nst_ctx* ctx, int kind, float lr_start, int lbfgs_max_eval, n
     if (r == NST_OK) r = oalloc(o, &o->losses, (size_t)NST_LOSS_ROW * o->levels + 1);
     o->own_g = o->g; o->own_losses = o->losses;
     if (r == NST_OK) r = oalloc(o, &o->scal, 4);
+    if (r == NST_OK && kind == NST_OPT_LBFGS) r = oalloc(o, &o->al_dev, (size_t)o->history);
     if (r == NST_OK && hipHostMalloc(reinterpret_cast<void**>(&o->pinned), (8 + (size_t)NST_LOSS_ROW * NST_MAX_LEVELS + 1) * sizeof(float), hipHostMallocDefault) != hipSuccess) r = NST_E_NOMEM;
     if (r == NST_OK && hipMalloc(reinterpret_cast<void**>(&o->scratch), 2 * RED_BLOCKS * sizeof(double)) != hipSuccess) r = NST_E_NOMEM;
     if (r == NST_OK && kind == NST_OPT_ADAM) {
@@ -374,7 +382,7 @@ void nst_opt_destroy(nst_opt* o) {
     if (!o) return;
     (void)hipSetDevice(nst_internal_device(o->ctx));
     (void)hipDeviceSynchronize();
-    float* ptrs[] = {o->own_g, o->own_losses, o->scal, o->m, o->v, o->d, o->prev_g, o->xinit, o->q};
+    float* ptrs[] = {o->own_g, o->own_losses, o->scal, o->al_dev, o->m, o->v, o->d, o->prev_g, o->xinit, o->q};
     for (float* p : ptrs) if (p) (void)hipFree(p);
     if (o->scratch) (void)hipFree(o->scratch);
     if (o->pinned) (void)hipHostFree(o->pinned);

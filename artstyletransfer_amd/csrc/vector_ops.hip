@@ -64,6 +64,93 @@ hipError_t launch_dot(const float* a, const float* b, size_t n, double* scratch,
     return hipGetLastError();
 }
 
+// dot product left as RED_BLOCKS double partials in `scratch` (the consumer below finishes it)
+hipError_t launch_dot_partial(const float* a, const float* b, size_t n, double* scratch, hipStream_t stream) {
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(RED_BLOCKS), dim3(256), 0, stream, a, b, n, scratch);
+    return hipGetLastError();
+}
+
+// ---- one history pair of the L-BFGS two-loop recursion (torch:optim/lbfgs.py:444-460), no host round trip -------
+// Finishes the dot product the previous launch left in `sin` (same order and rounding as sum_finish_kernel), forms the
+// pair's coefficient, applies y += coef * x and, in the same pass, leaves the partials of the NEXT pair's dot
+// product nxt . y in `sout` (same per-thread order as dot_partial_kernel, same grid).
+//   first loop  (second = 0): v = dot * ro = al_i (stored to al[0]);  coef = -al_i         (q -= al_i * y_i)
+//   second loop (second = 1): v = dot * ro = be_i;                     coef = al[0] - be_i  (r += (al_i - be_i) * s_i)
+// With a host-side scalar per pair the two loops cost 2 * history stream synchronisations per optimiser step.
+__global__ __launch_bounds__(256) void lbfgs_pair_kernel(const double* __restrict__ sin, float ro, float* __restrict__ al,
+                                                         int second, const float* __restrict__ x, float* __restrict__ y,
+                                                         const float* __restrict__ nxt, size_t n, double* __restrict__ sout) {
+    __shared__ double sh[4];
+    __shared__ float coef_sh;
+    const double r = vblock_sum(threadIdx.x < RED_BLOCKS ? sin[threadIdx.x] : 0.0, sh);
+    if (threadIdx.x == 0) {
+        const float v = (float)r * ro;
+        float c;
+        if (second) {
+            c = al[0] - v;
+        } else {
+            c = -v;
+            if (blockIdx.x == 0) al[0] = v;
+        }
+        coef_sh = c;
+    }
+    __syncthreads();
+    const float coef = coef_sh;
+    const size_t n4 = n / 4;
+    const f32x4* xv = reinterpret_cast<const f32x4*>(x);
+    f32x4* yv = reinterpret_cast<f32x4*>(y);
+    const f32x4* nv = reinterpret_cast<const f32x4*>(nxt);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // four elements' loads in flight per lane (256 workgroups x 4 waves cannot cover HBM latency one load at a time);
+    // the arithmetic keeps the one-element-at-a-time order, so the dot partials are those of dot_partial_kernel
+    constexpr int U = 4;
+    for (; i + (U - 1) * stride < n4; i += U * stride) {
+        f32x4 a[U], b[U], c[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            a[k] = xv[i + k * stride];
+            b[k] = yv[i + k * stride];
+            if (nxt) c[k] = nv[i + k * stride];
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            f32x4 r;
+            r[0] = b[k][0] + coef * a[k][0]; r[1] = b[k][1] + coef * a[k][1];
+            r[2] = b[k][2] + coef * a[k][2]; r[3] = b[k][3] + coef * a[k][3];
+            yv[i + k * stride] = r;
+            if (nxt) { s0 += c[k][0] * r[0]; s1 += c[k][1] * r[1]; s2 += c[k][2] * r[2]; s3 += c[k][3] * r[3]; }
+        }
+    }
+    for (; i < n4; i += stride) {
+        const f32x4 a = xv[i];
+        f32x4 b = yv[i];
+        b[0] = b[0] + coef * a[0]; b[1] = b[1] + coef * a[1]; b[2] = b[2] + coef * a[2]; b[3] = b[3] + coef * a[3];
+        yv[i] = b;
+        if (nxt) {
+            const f32x4 c = nv[i];
+            s0 += c[0] * b[0]; s1 += c[1] * b[1]; s2 += c[2] * b[2]; s3 += c[3] * b[3];
+        }
+    }
+    double s = ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (size_t i = n4 * 4; i < n; ++i) {
+            const float b = y[i] + coef * x[i];
+            y[i] = b;
+            if (nxt) s += (double)nxt[i] * (double)b;
+        }
+    if (nxt) {
+        const double rr = vblock_sum(s, sh);
+        if (threadIdx.x == 0) sout[blockIdx.x] = rr;
+    }
+}
+hipError_t launch_lbfgs_pair(const double* sin, float ro, float* al, int second, const float* x, float* y, const float* nxt,
+                             size_t n, double* sout, hipStream_t stream) {
+    hipLaunchKernelGGL(lbfgs_pair_kernel, dim3(RED_BLOCKS), dim3(256), 0, stream, sin, ro, al, second, x, y, nxt, n, sout);
+    return hipGetLastError();
+}
+
 // ---- max|a| and sum|a| ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void abs_partial_kernel(const float* __restrict__ a, size_t n,
                                                           double* __restrict__ scratch) {
