@@ -520,6 +520,42 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.bits_in), 0, bit_bytes, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.addend), 0, p.addend ? out_bytes : 0u, 0x00020000);
             const float lo_clamp = p.relu ? 0.f : -__builtin_inff();
+            if (!p.addend) {
+                // No addend (every input-gradient launch but the one below the content layer): ALL mask words of the
+                // tile first - the fragment registers are free now - and then the arithmetic and the stores, so the
+                // workgroup waits for one load latency instead of one per group of eight elements (stores to `out`
+                // keep the compiler from moving later loads above them, and all eight waves of the CU's only
+                // workgroup sit in this epilogue together, so nothing else hides those waits).
+                unsigned wv[2][16][NTW];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (NTW == 2) {
+                            const u32x2 w2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_bits, wbase, soff(mt, r, wrowB, wcolB), 0));
+                            wv[mt][r][0] = w2[0];
+                            wv[mt][r][NTW - 1] = w2[1];
+                        } else {
+                            wv[mt][r][0] = __builtin_amdgcn_raw_buffer_load_b32(rs_bits, wbase, soff(mt, r, wrowB, wcolB), 0);
+                        }
+                    }
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) {
+                    const float bv = p.bias ? p.bias[cg0 + nt * 32 + l31] : 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float v = fmaf(accx[mt][nt][r], LO_DOWN, accm[mt][nt][r]) * inv + bv;
+                            v = fmaxf(v + 0.f, lo_clamp);            // (+ 0: the absent addend, so that -0 sums as in the general form)
+                            v = ((wv[mt][r][nt] >> l31) & 1u) ? v : 0.f;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, vbase, soff(mt, r, rowB, colB) + nt * 128, 0);
+                            amax = fmaxf(amax, fabsf(v));
+                        }
+                }
+                record_amax();
+                return;
+            }
 #pragma unroll
             for (int nt = 0; nt < NTW; ++nt) {
                 const float bv = p.bias ? p.bias[cg0 + nt * 32 + l31] : 0.f;
