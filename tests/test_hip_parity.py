@@ -292,10 +292,12 @@ def test_closure_accuracy_vs_fp64_truth(eng, vgg_weights, h, w, nlev):
 
 
 @pytest.mark.parametrize("env", [{"NST_CONV": "bf16x3"}, {"NST_CONV": "f32"}, {"NST_BATCH": "0"}, {"NST_BATCH": "0", "NST_SINGLE_STREAM": "1"},
-                                 {"NST_CONV": "f32", "NST_BATCH": "0"}])
+                                 {"NST_CONV": "f32", "NST_BATCH": "0"}, {"NST_BATCH": "0", "NST_H2_BAND_ROWS": "16"},
+                                 {"NST_BATCH": "0", "NST_SINGLE_STREAM": "1", "NST_H2_BAND_ROWS": "32"}])
 def test_closure_execution_modes_agree(eng, vgg_weights, monkeypatch, env):
     """The alternative schedules / arithmetic (fp32-MFMA convs; one launch per level on per-level streams or on one
-    stream) must give the default path's closure (f16x2 convs, one launch per layer over all levels)."""
+    stream; the row-band launches that tensors beyond 4 GiB take, forced onto these small images) must give the
+    default path's closure (f16x2 convs, one launch per layer over all levels)."""
     from artstyletransfer_amd.engine import StyleEngine
     c, s = _levels(128, 192, 3, 1), _levels(96, 160, 3, 2)
     x = dev(cpu_ref.prepare_img((0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(128, 192, seed=9)).astype(np.float32)))
@@ -327,7 +329,9 @@ def test_f16x2_vs_exact_f32_mfma_random_geometries(vgg_weights, monkeypatch, geo
     c, s = _levels(h, w, nlev, 1), _levels(hs, ws, nlev, 2)
     x = dev(cpu_ref.prepare_img((0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(h, w, seed=9)).astype(np.float32)))
     res = []
-    for env in ({"NST_CONV": "f32", "NST_BATCH": "0"}, {"NST_CONV": "f16x2", "NST_BATCH": "1"}):
+    for env in ({"NST_CONV": "f32", "NST_BATCH": "0", "NST_H2_BAND_ROWS": "0"},
+                {"NST_CONV": "f16x2", "NST_BATCH": "1", "NST_H2_BAND_ROWS": "0"},
+                {"NST_CONV": "f16x2", "NST_BATCH": "0", "NST_H2_BAND_ROWS": "16"}):      # per-level launches in 16-row bands
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         e = StyleEngine(vgg_weights, 0)
@@ -337,11 +341,15 @@ def test_f16x2_vs_exact_f32_mfma_random_geometries(vgg_weights, monkeypatch, geo
             res.append((g.cpu().numpy(), l.cpu().numpy()))
         finally:
             e.close()
-    (g0, l0), (g1, l1) = res
-    np.testing.assert_allclose(l1[-1], l0[-1], rtol=1e-5)
-    np.testing.assert_allclose(l1[:-1].reshape(nlev, 4)[:, 0], l0[:-1].reshape(nlev, 4)[:, 0], rtol=2e-5)
-    assert np.isfinite(g1).all()
-    assert rel_l2(g1, g0) < GRAD_RTOL
+    g0, l0 = res[0]
+    for g1, l1 in res[1:]:
+        np.testing.assert_allclose(l1[-1], l0[-1], rtol=1e-5)
+        np.testing.assert_allclose(l1[:-1].reshape(nlev, 4)[:, 0], l0[:-1].reshape(nlev, 4)[:, 0], rtol=2e-5)
+        assert np.isfinite(g1).all()
+        assert rel_l2(g1, g0) < GRAD_RTOL
+    # the banded per-level launches compute what the batched launches compute
+    np.testing.assert_allclose(res[2][1], res[1][1], rtol=1e-6)
+    assert rel_l2(res[2][0], res[1][0]) < 1e-5
 
 
 @pytest.mark.parametrize("H0,W0,world", [(384, 256, 2), (384, 256, 3), (512, 208, 4), (390, 250, 2), (471, 183, 3)])
