@@ -179,6 +179,10 @@ def main():
     ap.add_argument("--time-all-kernels", action="store_true", help="event pairs around every launch (slower)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
+    ap.add_argument("--jobs-per-gpu", type=int, default=1,
+                    help="mode 'jobs' only: that many independent jobs per GPU, each on its own HIP stream and host "
+                         "thread (the scheduler's simultaneous_tasks_count; 2 gives ~1.09x the aggregate rate). The "
+                         "default, 1, is the configuration BASELINE quotes")
     ap.add_argument("--mode", default="jobs", choices=["jobs", "levels", "stripes"],
                     help="N>1: 'jobs' = one independent job per GPU (weak scaling, no collective); 'levels' = ONE "
                          "job, pyramid levels sharded over the ranks, RCCL all-reduce of the pixel gradient per "
@@ -216,40 +220,80 @@ def main():
         opt.shard_stripes(rank, world, job_host[3], prep(job_host[0][0]), prep(job_host[1][0]), dist)
     cw, sw, tvw = cfg.content_weight, cfg.style_weight, cfg.tv_weight
     H, W = eng.shape
-    # per-step image yield as NeuralStyleTransfer.process does it: un-prepare on the device, D2H into pinned
-    # memory on a side stream, so the copy of step k runs under the closures of step k+1; it is awaited before
-    # the next yield (two host buffers)
-    img_host = [torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True) for _ in range(2)]
-    copy_stream = torch.cuda.Stream()
-    copy_done = [None, None]
     per_step = 2 if args.optimizer == "lbfgs" else 1
 
+    class JobLoop:
+        """One job's optimiser loop with the per-step image yield as NeuralStyleTransfer.process does it: un-prepare on
+        the device, D2H into pinned memory on a side stream, so the copy of step k runs under the closures of step
+        k+1; it is awaited before the next yield (two host buffers)."""
+
+        def __init__(self, eng, x, opt, stream=None):
+            self.eng, self.x, self.opt, self.stream = eng, x, opt, stream
+            self.img_host = [torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+            self.copy_stream = torch.cuda.Stream()
+            self.copy_done = [None, None]
+            self.result = (0, None)
+
+        def run(self, closures: int):
+            if self.stream is not None:                      # an extra job: its own stream (per-thread current stream)
+                with torch.cuda.stream(self.stream):
+                    self.result = self._run(closures)
+            else:
+                self.result = self._run(closures)
+            return self.result
+
+        def _run(self, closures: int):
+            done = 0
+            last = None
+            k = 0
+            while done < closures:
+                info, rows = self.opt.step(self.x, cw, sw, tvw, want_losses=True)
+                done += info.closures
+                last = rows
+                if not args.no_yield:
+                    snap = self.eng.unprepare_img(self.x)
+                    ready = torch.cuda.Event()
+                    ready.record()
+                    if self.copy_done[k] is not None:
+                        self.copy_done[k].synchronize()           # the consumer is done with this host buffer
+                    with torch.cuda.stream(self.copy_stream):
+                        self.copy_stream.wait_event(ready)
+                        self.img_host[k].copy_(snap, non_blocking=True)
+                        snap.record_stream(self.copy_stream)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                    self.copy_done[k] = ev
+                    k ^= 1
+            for ev in self.copy_done:
+                if ev is not None:
+                    ev.synchronize()
+            return done, last
+
+    jobs = [JobLoop(eng, x, opt)]
+    extra = []
+    if args.jobs_per_gpu > 1:
+        if sharded:
+            raise SystemExit("--jobs-per-gpu applies to --mode jobs")
+        for j in range(1, args.jobs_per_gpu):
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                e2, x2, _, _ = build_job(args.levels, world * j + rank, local_rank)
+                o2 = PixelOptimizer(e2, args.optimizer, 10.0, 1)
+            extra.append((e2, o2))
+            jobs.append(JobLoop(e2, x2, o2, st))
+        torch.cuda.synchronize()
+
     def run(closures: int):
-        done = 0
-        last = None
-        k = 0
-        while done < closures:
-            info, rows = opt.step(x, cw, sw, tvw, want_losses=True)
-            done += info.closures
-            last = rows
-            if not args.no_yield:
-                snap = eng.unprepare_img(x)
-                ready = torch.cuda.Event()
-                ready.record()
-                if copy_done[k] is not None:
-                    copy_done[k].synchronize()           # the consumer is done with this host buffer
-                with torch.cuda.stream(copy_stream):
-                    copy_stream.wait_event(ready)
-                    img_host[k].copy_(snap, non_blocking=True)
-                    snap.record_stream(copy_stream)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                copy_done[k] = ev
-                k ^= 1
-        for ev in copy_done:
-            if ev is not None:
-                ev.synchronize()
-        return done, last
+        """All jobs of this rank, each for `closures` closure evaluations; returns (closures done by all, last rows of job 0)."""
+        if len(jobs) == 1:
+            return jobs[0].run(closures)
+        import threading
+        threads = [threading.Thread(target=j.run, args=(closures,)) for j in jobs]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        return sum(j.result[0] for j in jobs), jobs[0].result[1]
 
     def barrier():
         if dist is not None:
@@ -258,6 +302,8 @@ def main():
 
     steps = max(per_step, (args.steps // per_step) * per_step)
     run(max(args.warmup, 0))
+    if args.jobs_per_gpu > 1:
+        args.no_kernel_timing = True       # launch durations are not a kernel's own while another job shares the chip
     if not args.no_kernel_timing:
         # HIP events around the dominant kernel's launches (24 per closure) in every fourth closure of the timed region:
         # a pair around each of them in every closure costs 5 % of the closure rate, around all ~50 launches 8 %
@@ -295,12 +341,12 @@ def main():
                                    f"seeded synthetic VGG19 weights, per-step image yield "
                                    f"{'off' if args.no_yield else 'on'}",
                        "iter": "one closure evaluation (forward + losses + backward of every level) + its share of the optimiser update",
-                       "parallelism": ("1 GPU" if world == 1 else
+                       "parallelism": (("1 GPU" if args.jobs_per_gpu == 1 else f"1 GPU, {args.jobs_per_gpu} jobs on their own streams") if world == 1 else
                                        (f"levels sharded over {world} ranks, RCCL all-reduce of the pixel gradient"
                                         if args.mode == "levels" else
                                         f"top level in {world} stripes (+96-row halo), lower levels by level; all-reduce of the "
                                         f"Gram/content/TV sums and of the pixel gradient per closure")
-                                       if sharded else "1 job per GPU, no collective"),
+                                       if sharded else (f"{args.jobs_per_gpu} job(s) per GPU on their own streams, no collective" if args.jobs_per_gpu > 1 else "1 job per GPU, no collective")),
                        "final_loss": float(last_rows[-1][-1]) if last_rows is not None else None,
                        "job_setup_ms_on_device": round(getattr(cfg, "job_setup_ms", 0.0), 1)},
             "closure_tflops_algorithmic": closure_flops / 1e12,
@@ -338,6 +384,9 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(job_host, cfg, args.cpu_closures)
         print(json.dumps(out), flush=True)
+    for e2, o2 in extra:
+        o2.close()
+        e2.close()
     opt.close()
     eng.close()
     if dist is not None:
