@@ -81,7 +81,9 @@ struct H2Cfg {
     static_assert(KC == 16 || KC == 32, "one or two k-steps per stage");
     static_assert(NT == 512 || NT == 256, "eight or four waves per workgroup");
     static_assert(B_UNITS % NT == 0, "every lane stages the same number of weight units (no predication)");
-    static_assert(LDS_BYTES <= (NT == 512 ? 160 : 80) * 1024, "LDS budget (two 256-thread workgroups share a CU)");
+    // (the 256-thread shapes with 16-channel chunks fit twice on a CU; the 4-row shape is for launches with fewer
+    // workgroups than CUs and may take more than half of it)
+    static_assert(LDS_BYTES <= ((NT == 512 || TH == 4) ? 160 : 80) * 1024, "LDS budget (two 256-thread workgroups share a CU)");
 };
 
 // Power-of-two scale that brings the recorded absmax (64 slots of non-negative float bit patterns) into
@@ -787,12 +789,17 @@ hipError_t conv_h2_init_device() {
     if (e == hipSuccess) e = init_one<16, 64, 2, 16, true>();
     if (e == hipSuccess) e = init_one<8, 128, 2, 16, false>();
     if (e == hipSuccess) e = init_one<8, 128, 2, 16, true>();
+    if (e == hipSuccess) e = init_one<4, 128, 1, 32, false>();
+    if (e == hipSuccess) e = init_one<4, 128, 1, 32, true>();
     return e;
 }
 
-// a 128-channel launch whose 16-row tiles cannot fill 256 CUs twice over uses 8-row tiles
+// a 128-channel launch whose 16-row tiles cannot fill 256 CUs twice over uses 8-row tiles, and 4-row tiles (256
+// threads, two workgroups per CU) when even those leave most of the chip idle: the deep layers of small jobs, whose
+// few workgroups each walk the whole K = 4 608 - the launch lasts as long as ONE workgroup does
 static int h2_tile_rows(int Cout, long blocks16) {
     if (Cout % 128 != 0) return 16;
+    if (blocks16 < 100) return 4;
     return blocks16 < 400 ? 8 : 16;
 }
 
@@ -844,6 +851,7 @@ hipError_t launch_conv_h2_batch(const ConvBatch& b0, hipStream_t stream) {
     const int blocks = tiles * (b.Cout / bn);
     if (!wide) launch_batch_cfg<16, 64, 2, 16>(b, blocks, stream);
     else if (shortk) launch_batch_cfg<8, 128, 2, 16>(b, blocks, stream);
+    else if (th == 4) launch_batch_cfg<4, 128, 1, 32>(b, blocks, stream);
     else if (th == 8) launch_batch_cfg<8, 128, 1, 32>(b, blocks, stream);
     else launch_batch_cfg<16, 128, 2, 32>(b, blocks, stream);
     return hipGetLastError();
@@ -897,6 +905,7 @@ hipError_t launch_conv_h2(const ConvParams& p0, hipStream_t stream) {
         const int blocks = q.tiles_x * q.tiles_y * (p.Cout / bn);
         if (!wide) launch_single_cfg<16, 64, 2, 16>(q, blocks, stream);
         else if (shortk) launch_single_cfg<8, 128, 2, 16>(q, blocks, stream);
+        else if (th == 4) launch_single_cfg<4, 128, 1, 32>(q, blocks, stream);
         else if (th == 8) launch_single_cfg<8, 128, 1, 32>(q, blocks, stream);
         else launch_single_cfg<16, 128, 2, 32>(q, blocks, stream);
         const hipError_t e = hipGetLastError();
