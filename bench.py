@@ -301,6 +301,11 @@ def main():
         torch.cuda.synchronize()
 
     steps = max(per_step, (args.steps // per_step) * per_step)
+    # part of the set-up, not of the --warmup steps: one closure evaluation that leaves x and the optimiser untouched, so
+    # that the one-off cold launch of the backward kernels (code-object load, ~17 ms) never lands in a timed region
+    for j in jobs:
+        j.eng.closure(j.x, cw, sw, tvw)
+    torch.cuda.synchronize()
     run(max(args.warmup, 0))
     if args.jobs_per_gpu > 1:
         args.no_kernel_timing = True       # launch durations are not a kernel's own while another job shares the chip
