@@ -485,7 +485,15 @@ __device__ __forceinline__ void gram_finish_body(const float* __restrict__ part,
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[j];
         }
-        for (; k < nslabs; k += 8) s += part[(size_t)k * CC + e];
+        // the rest four at a time, slabs beyond the last read as +0 (x + 0 = x: same sum, same order) - with 25 slabs
+        // (C = 512) the loop above never runs, and one load in flight per lane left this pass latency-bound
+        for (; k < nslabs; k += 32) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (k + 8 * j < nslabs) ? part[(size_t)(k + 8 * j) * CC + e] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += v[j];
+        }
     }
     sh[grp][el] = s;
     __syncthreads();
