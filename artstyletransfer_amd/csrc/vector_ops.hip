@@ -77,12 +77,24 @@ hipError_t launch_dot_partial(const float* a, const float* b, size_t n, double* 
 //   first loop  (second = 0): v = dot * ro = al_i (stored to al[0]);  coef = -al_i         (q -= al_i * y_i)
 //   second loop (second = 1): v = dot * ro = be_i;                     coef = al[0] - be_i  (r += (al_i - be_i) * s_i)
 // With a host-side scalar per pair the two loops cost 2 * history stream synchronisations per optimiser step.
-__global__ __launch_bounds__(256) void lbfgs_pair_kernel(const double* __restrict__ sin, float ro, float* __restrict__ al,
+template <int NT>
+__global__ __launch_bounds__(NT) void lbfgs_pair_kernel(const double* __restrict__ sin, float ro, float* __restrict__ al,
                                                          int second, const float* __restrict__ x, float* __restrict__ y,
                                                          const float* __restrict__ nxt, size_t n, double* __restrict__ sout) {
-    __shared__ double sh[4];
+    __shared__ double sh[NT / 64];
     __shared__ float coef_sh;
-    const double r = vblock_sum(threadIdx.x < RED_BLOCKS ? sin[threadIdx.x] : 0.0, sh);
+    // block sum over NT / 64 waves, waves added in order
+    auto block_sum = [&](double v) -> double {
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double t = 0.0;
+        if (threadIdx.x == 0)
+            for (int w = 0; w < NT / 64; ++w) t += sh[w];
+        __syncthreads();
+        return t;
+    };
+    const double r = block_sum(threadIdx.x < RED_BLOCKS ? sin[threadIdx.x] : 0.0);
     if (threadIdx.x == 0) {
         const float v = (float)r * ro;
         float c;
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(256) void lbfgs_pair_kernel(const double* __restric
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     // four elements' loads in flight per lane (256 workgroups x 4 waves cannot cover HBM latency one load at a time);
     // the arithmetic keeps the one-element-at-a-time order, so the dot partials are those of dot_partial_kernel
-    constexpr int U = 4;
+    constexpr int U = (NT >= 1024) ? 2 : 4;
     for (; i + (U - 1) * stride < n4; i += U * stride) {
         f32x4 a[U], b[U], c[U];
 #pragma unroll
@@ -141,13 +153,14 @@ __global__ __launch_bounds__(256) void lbfgs_pair_kernel(const double* __restric
             if (nxt) s += (double)nxt[i] * (double)b;
         }
     if (nxt) {
-        const double rr = vblock_sum(s, sh);
+        const double rr = block_sum(s);
         if (threadIdx.x == 0) sout[blockIdx.x] = rr;
     }
 }
 hipError_t launch_lbfgs_pair(const double* sin, float ro, float* al, int second, const float* x, float* y, const float* nxt,
                              size_t n, double* sout, hipStream_t stream) {
-    hipLaunchKernelGGL(lbfgs_pair_kernel, dim3(RED_BLOCKS), dim3(256), 0, stream, sin, ro, al, second, x, y, nxt, n, sout);
+    constexpr int NT = 1024;     // 16 waves per CU: this pass is pure streaming and 4 waves per CU left it latency-bound
+    hipLaunchKernelGGL(lbfgs_pair_kernel<NT>, dim3(RED_BLOCKS), dim3(NT), 0, stream, sin, ro, al, second, x, y, nxt, n, sout);
     return hipGetLastError();
 }
 
