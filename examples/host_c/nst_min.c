@@ -1,0 +1,123 @@
+/* Minimal C host of the MI355X style-transfer engine: no Python, no torch - only include/nst_hip.h,
+ * libnst_hip.so and the HIP runtime for the caller-owned device buffers.  It is the call sequence a
+ * non-Python front-end binds: context -> job geometry -> targets ->
+ * optimiser -> steps, on a small synthetic job (seeded pseudo-random VGG19 weights and images), and it
+ * prints the loss of every optimiser step.
+ *
+ *   gcc -std=c99 -O2 -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ examples/host_c/nst_min.c \
+ *       -Lartstyletransfer_amd -lnst_hip -L/opt/rocm/lib -lamdhip64 -lm \
+ *       -Wl,-rpath,$PWD/artstyletransfer_amd -Wl,-rpath,/opt/rocm/lib -o /tmp/nst_min
+ *   /tmp/nst_min [adam|lbfgs] [steps]
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <hip/hip_runtime_api.h>
+
+#include "nst_hip.h"
+
+static const int kCin[NST_VGG19_CONVS] = {3, 64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512};
+static const int kCout[NST_VGG19_CONVS] = {64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512};
+
+static unsigned long long rng_state = 0x9E3779B97F4A7C15ull;
+static float uniform01(void) { /* xorshift64* */
+    rng_state ^= rng_state >> 12; rng_state ^= rng_state << 25; rng_state ^= rng_state >> 27;
+    return (float)((rng_state * 0x2545F4914F6CDD1Dull) >> 40) / 16777216.0f;
+}
+static float gaussian(void) {
+    float u1 = uniform01(), u2 = uniform01();
+    if (u1 < 1e-7f) u1 = 1e-7f;
+    return sqrtf(-2.0f * logf(u1)) * cosf(6.28318530718f * u2);
+}
+
+#define CHECK_NST(call)                                                                          \
+    do {                                                                                         \
+        int rc_ = (call);                                                                        \
+        if (rc_ != NST_OK) {                                                                     \
+            fprintf(stderr, "%s -> %d: %s\n", #call, rc_, nst_last_error(ctx));                  \
+            return 1;                                                                            \
+        }                                                                                        \
+    } while (0)
+#define CHECK_HIP(call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) { fprintf(stderr, "%s -> %s\n", #call, hipGetErrorString(e_)); return 1; } \
+    } while (0)
+
+/* smooth synthetic HWC image in [0,1], prepared as the reference's prepare_img does: x*255 - mean, CHW */
+static float* prepared_image(nst_ctx* ctx, int h, int w, float phase) {
+    static const float mean[3] = {123.675f, 116.28f, 103.53f};
+    size_t n = (size_t)3 * h * w;
+    float* host = (float*)malloc(n * sizeof(float));
+    float* dev = NULL;
+    (void)ctx;
+    for (int c = 0; c < 3; ++c)
+        for (int y = 0; y < h; ++y)
+            for (int x = 0; x < w; ++x) {
+                float v = 0.5f + 0.25f * sinf(0.11f * x + phase + c) * cosf(0.07f * y - phase) + 0.2f * (uniform01() - 0.5f);
+                host[((size_t)c * h + y) * w + x] = v * 255.0f - mean[c];
+            }
+    if (hipMalloc((void**)&dev, n * sizeof(float)) != hipSuccess) { free(host); return NULL; }
+    if (hipMemcpy(dev, host, n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) { free(host); return NULL; }
+    free(host);
+    return dev;
+}
+
+int main(int argc, char** argv) {
+    const int kind = (argc > 1 && strcmp(argv[1], "adam") == 0) ? NST_OPT_ADAM : NST_OPT_LBFGS;
+    const int steps = argc > 2 ? atoi(argv[2]) : 6;
+    const int H = 96, W = 144, levels = 2;
+    nst_ctx* ctx = NULL;
+    nst_opt* opt = NULL;
+    int ndev = 0;
+
+    if (nst_device_count(&ndev) != NST_OK || ndev < 1) { fprintf(stderr, "no GPU: the engine has no CPU path\n"); return 2; }
+
+    /* seeded synthetic weights: N(0, 2 / (Cout * 9)), zero biases (torchvision order conv1_1..conv5_1) */
+    float* w[NST_VGG19_CONVS];
+    float* b[NST_VGG19_CONVS];
+    for (int l = 0; l < NST_VGG19_CONVS; ++l) {
+        size_t nw = (size_t)kCout[l] * kCin[l] * 9;
+        float sd = sqrtf(2.0f / (kCout[l] * 9.0f));
+        w[l] = (float*)malloc(nw * sizeof(float));
+        b[l] = (float*)calloc((size_t)kCout[l], sizeof(float));
+        for (size_t i = 0; i < nw; ++i) w[l][i] = sd * gaussian();
+    }
+    CHECK_NST(nst_ctx_create(0, (const float* const*)w, (const float* const*)b, &ctx));
+    for (int l = 0; l < NST_VGG19_CONVS; ++l) { free(w[l]); free(b[l]); }
+
+    CHECK_NST(nst_job_configure(ctx, levels, H, W));
+    for (int l = 0; l < levels; ++l) {
+        int h = H >> l, ww = W >> l;
+        float* content = prepared_image(ctx, h, ww, 0.3f);
+        float* style = prepared_image(ctx, h + 10, ww - 6, 1.7f);       /* a style image of its own size */
+        if (!content || !style) { fprintf(stderr, "device allocation failed\n"); return 1; }
+        CHECK_NST(nst_level_set_targets(ctx, l, content, style, h + 10, ww - 6, NULL));
+        CHECK_HIP(hipDeviceSynchronize());
+        CHECK_HIP(hipFree(content));
+        CHECK_HIP(hipFree(style));
+    }
+    float* x = prepared_image(ctx, H, W, 0.9f);                          /* the optimised pixels: caller-owned */
+    if (!x) { fprintf(stderr, "device allocation failed\n"); return 1; }
+
+    CHECK_NST(nst_opt_create(ctx, kind, kind == NST_OPT_ADAM ? 10.0f : 1.0f, 26, &opt));
+    float first = 0.f, last = 0.f;
+    for (int s = 0; s < steps; ++s) {
+        nst_step_info info;
+        float rows[26 * (NST_LOSS_ROW * 2 + 1)];
+        CHECK_NST(nst_opt_step(opt, x, 1e3f, 4e5f, 1e2f, rows, 26, &info, NULL));
+        CHECK_HIP(hipDeviceSynchronize());
+        printf("step %d: loss %.6e closures %d (total %d) accepted %d lr %.4f\n", s, info.loss, info.closures,
+               info.total_closures, info.accepted, info.lr);
+        if (s == 0) first = info.loss;
+        last = info.loss;
+        if (!(info.loss == info.loss) || info.loss > 3.0e38f) { fprintf(stderr, "non-finite loss\n"); return 1; }
+    }
+    printf("first %.6e last %.6e %s\n", first, last, last < first ? "DECREASED" : "NOT-DECREASED");
+    nst_opt_destroy(opt);
+    nst_ctx_destroy(ctx);
+    CHECK_HIP(hipFree(x));
+    return last < first ? 0 : 3;
+}
