@@ -231,6 +231,12 @@ hipError_t launch_dot_partial(const float* a, const float* b, size_t n, double* 
 // one history pair of the L-BFGS two-loop recursion on the device (see vector_ops.hip)
 hipError_t launch_lbfgs_pair(const double* sin, float ro, float* al, int second, const float* x, float* y, const float* nxt,
                              size_t n, double* sout, hipStream_t stream);
+// L-BFGS direction from inner products (vector_ops.hip): out[j*3 + {0,1,2}] = vecs[j] . {a, b, c};  d = h q0 + sum coef[j] vecs[j]
+int multi_dot_blocks(size_t n);                                       // scratch: multi_dot_blocks(n) * nvec * 3 doubles
+hipError_t launch_multi_dot(const float* const* vecs_dev, int nvec, const float* a, const float* b, const float* c, size_t n,
+                            double* scratch, float* out, hipStream_t stream);
+hipError_t launch_multi_axpy(const float* const* vecs_dev, const float* coef_dev, int nvec, const float* q0, float h, float* d,
+                             size_t n, hipStream_t stream);
 hipError_t launch_axpy(float alpha, const float* x, float* y, size_t n, hipStream_t stream);               // y += alpha*x
 hipError_t launch_axpy_dev(const float* alpha_dev, float sign, const float* x, float* y, size_t n, hipStream_t stream);
 hipError_t launch_scale_copy(float alpha, const float* x, float* y, size_t n, hipStream_t stream);         // y = alpha*x

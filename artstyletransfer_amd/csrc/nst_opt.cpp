@@ -37,6 +37,16 @@ struct nst_opt {
     double* scratch = nullptr;   // 2*RED_BLOCKS
     float* scal = nullptr;       // 4 floats
     float* al_dev = nullptr;     // L-BFGS: the al_i of the two-loop recursion, one per history pair
+    // direction from inner products (default; NST_LBFGS_GRAM=0 selects the sequential recursion): SY[i][j] = s_i . y_j and
+    // YY[i][j] = y_i . y_j kept on the host, one multi-dot pass and one multi-axpy pass over the history per step
+    // instead of 2 launches per pair (update at 100 pairs, L=2: 3.5 -> 1.5 ms per step)
+    bool gram_mode = false;
+    const float** vec_dev = nullptr;   // 2*history device pointers: y_0..y_{m-1}, s_0..s_{m-1}
+    float* coef_dev = nullptr;         // 2*history coefficients of the direction
+    double* md_scratch = nullptr;      // multi_dot_blocks(n) * 2*history * 3
+    float* md_out = nullptr;           // 2*history * 3
+    unsigned char* pin2 = nullptr;     // page-locked staging: pointers | coefficients | results
+    std::vector<double> SY, YY;        // history x history, row-major
     float* pinned = nullptr;     // page-locked host staging for the scalar read-backs (pageable targets make
                                  // hipMemcpyAsync stage through an internal buffer: ~50 us per read-back)
     // adam
@@ -253,6 +263,59 @@ int strong_wolfe(nst_opt* o, float* x, double t, float f, float gtd, float d_nor
     return NST_OK;
 }
 
+// d = -H g by the two-loop recursion (lbfgs.py:444-460) carried out on inner products: with q0 = -g,
+//   al_i = ro_i (s_i.q0 - sum_{j>i} al_j s_i.y_j)                                   (first loop, i = m-1 .. 0)
+//   be_i = ro_i (H (y_i.q0 - sum_j al_j y_j.y_i) + sum_{j<i} (al_j - be_j) s_j.y_i)  (second loop, i = 0 .. m-1)
+//   d = H q0 - H sum_j al_j y_j + sum_j (al_j - be_j) s_j
+// One multi-dot pass gives s_i.q0, y_i.q0 and, for a new pair k, the new row / column of SY and YY.
+int gram_direction(nst_opt* o, bool new_pair, hipStream_t s) {
+    const int m = (int)o->old_dirs.size();
+    const int Hh = o->history;
+    const float Hd = o->H_is_one ? 1.f : o->H_diag;
+    OHIP(o, launch_scale_copy(-1.f, o->g, o->q, o->n, s));       // q0 = -g
+    if (m == 0) {
+        OHIP(o, launch_scale_copy(Hd, o->q, o->d, o->n, s));
+        return NST_OK;
+    }
+    const float** hp = reinterpret_cast<const float**>(o->pin2);
+    float* hcoef = reinterpret_cast<float*>(o->pin2 + 2 * (size_t)Hh * sizeof(float*));
+    float* hres = hcoef + 2 * (size_t)Hh;
+    for (int j = 0; j < m; ++j) { hp[j] = o->old_dirs[j]; hp[m + j] = o->old_stps[j]; }
+    OHIP(o, hipMemcpyAsync(o->vec_dev, hp, 2 * (size_t)m * sizeof(float*), hipMemcpyHostToDevice, s));
+    const float* a = new_pair ? o->old_stps[m - 1] : o->q;
+    const float* b = new_pair ? o->old_dirs[m - 1] : o->q;
+    OHIP(o, launch_multi_dot(o->vec_dev, 2 * m, a, b, o->q, o->n, o->md_scratch, o->md_out, s));
+    OHIP(o, hipMemcpyAsync(hres, o->md_out, 2 * (size_t)m * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+    OHIP(o, hipStreamSynchronize(s));
+    auto SY = [&](int i, int j) -> double& { return o->SY[(size_t)i * Hh + j]; };
+    auto YY = [&](int i, int j) -> double& { return o->YY[(size_t)i * Hh + j]; };
+    if (new_pair) {
+        const int k = m - 1;
+        for (int j = 0; j < m; ++j) {
+            SY(k, j) = hres[(size_t)j * 3 + 0];                       // s_k . y_j
+            YY(k, j) = YY(j, k) = hres[(size_t)j * 3 + 1];            // y_k . y_j
+            SY(j, k) = hres[(size_t)(m + j) * 3 + 1];                 // s_j . y_k
+        }
+    }
+    std::vector<double> al(m), be(m);
+    for (int i = m - 1; i >= 0; --i) {
+        double v = hres[(size_t)(m + i) * 3 + 2];                     // s_i . q0
+        for (int j = i + 1; j < m; ++j) v -= al[j] * SY(i, j);
+        al[i] = (double)o->ro[i] * v;
+    }
+    for (int i = 0; i < m; ++i) {
+        double yq = hres[(size_t)i * 3 + 2];                          // y_i . q0
+        for (int j = 0; j < m; ++j) yq -= al[j] * YY(j, i);
+        double v = (double)Hd * yq;
+        for (int j = 0; j < i; ++j) v += (al[j] - be[j]) * SY(j, i);
+        be[i] = (double)o->ro[i] * v;
+    }
+    for (int j = 0; j < m; ++j) { hcoef[j] = (float)(-(double)Hd * al[j]); hcoef[m + j] = (float)(al[j] - be[j]); }
+    OHIP(o, hipMemcpyAsync(o->coef_dev, hcoef, 2 * (size_t)m * sizeof(float), hipMemcpyHostToDevice, s));
+    OHIP(o, launch_multi_axpy(o->vec_dev, o->coef_dev, 2 * m, o->q, Hd, o->d, o->n, s));
+    return NST_OK;
+}
+
 int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t s, nst_step_info* info) {
     const double lr = o->lr;                                     // read before the closure decays it (lbfgs.py:349)
     float loss;
@@ -269,6 +332,7 @@ int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t 
         for (float* p : o->old_stps) o->spare.push_back(p);
         o->old_dirs.clear(); o->old_stps.clear(); o->ro.clear();
         o->H_is_one = true; o->H_diag = 1.f;
+        if (o->gram_mode) { std::fill(o->SY.begin(), o->SY.end(), 0.0); std::fill(o->YY.begin(), o->YY.end(), 0.0); }
     } else {
         // y = g - prev_g ; s = d * t
         float* y; float* st;
@@ -281,16 +345,30 @@ int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t 
         OHIP(o, launch_scale_copy((float)o->t, o->d, st, o->n, s));
         float ys, yy;
         OCHK(dot2(o, y, st, y, y, s, &ys, &yy));
+        bool new_pair = false;
         if (ys > 1e-10f) {
             if ((int)o->old_dirs.size() == o->history) {
                 o->spare.push_back(o->old_dirs.front()); o->spare.push_back(o->old_stps.front());
                 o->old_dirs.erase(o->old_dirs.begin()); o->old_stps.erase(o->old_stps.begin()); o->ro.erase(o->ro.begin());
+                if (o->gram_mode) {
+                    // the oldest pair leaves: rows / columns move up-left
+                    const int Hh = o->history;
+                    for (int i = 0; i + 1 < Hh; ++i)
+                        for (int j = 0; j + 1 < Hh; ++j) {
+                            o->SY[(size_t)i * Hh + j] = o->SY[(size_t)(i + 1) * Hh + j + 1];
+                            o->YY[(size_t)i * Hh + j] = o->YY[(size_t)(i + 1) * Hh + j + 1];
+                        }
+                }
             }
             o->old_dirs.push_back(y); o->old_stps.push_back(st); o->ro.push_back(1.0f / ys);
             o->H_diag = ys / yy; o->H_is_one = false;
+            new_pair = true;
         } else {
             o->spare.push_back(y); o->spare.push_back(st);
         }
+        if (o->gram_mode) {
+            OCHK(gram_direction(o, new_pair, s));
+        } else {
         // two-loop recursion (lbfgs.py:444-460) without a host round trip per pair: every launch finishes the previous
         // launch's dot product, applies its pair's update and leaves the partials of the next pair's dot product
         // (vector_ops.hip::lbfgs_pair_kernel).  The two halves of `scratch` alternate as the partials buffer.
@@ -312,6 +390,7 @@ int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t 
             OHIP(o, launch_lbfgs_pair(pp[cur], o->ro[i], o->al_dev + i, 1, o->old_stps[i], o->d,
                                       i + 1 < num_old ? o->old_dirs[i + 1] : nullptr, o->n, pp[cur ^ 1], s));
             cur ^= 1;
+        }
         }
     }
     OHIP(o, launch_copy(o->g, o->prev_g, o->n, s));
@@ -360,6 +439,19 @@ int nst_opt_create(nst_ctx* ctx, int kind, float lr_start, int lbfgs_max_eval, n
     o->own_g = o->g; o->own_losses = o->losses;
     if (r == NST_OK) r = oalloc(o, &o->scal, 4);
     if (r == NST_OK && kind == NST_OPT_LBFGS) r = oalloc(o, &o->al_dev, (size_t)o->history);
+    const char* gm = std::getenv("NST_LBFGS_GRAM");      // "0": the sequential recursion, one fused launch per pair and loop
+    if (r == NST_OK && kind == NST_OPT_LBFGS && !(gm && gm[0] == '0')) {
+        const size_t H2 = 2 * (size_t)o->history;
+        o->gram_mode = true;
+        o->SY.assign((size_t)o->history * o->history, 0.0);
+        o->YY.assign((size_t)o->history * o->history, 0.0);
+        if (hipMalloc(reinterpret_cast<void**>(&o->vec_dev), H2 * sizeof(float*)) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void**>(&o->md_scratch), (size_t)multi_dot_blocks(o->n) * H2 * 3 * sizeof(double)) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void**>(&o->pin2), H2 * (sizeof(float*) + 4 * sizeof(float)), hipHostMallocDefault) != hipSuccess)
+            r = NST_E_NOMEM;
+        if (r == NST_OK) r = oalloc(o, &o->coef_dev, H2);
+        if (r == NST_OK) r = oalloc(o, &o->md_out, H2 * 3);
+    }
     if (r == NST_OK && hipHostMalloc(reinterpret_cast<void**>(&o->pinned), (8 + (size_t)NST_LOSS_ROW * NST_MAX_LEVELS + 1) * sizeof(float), hipHostMallocDefault) != hipSuccess) r = NST_E_NOMEM;
     if (r == NST_OK && hipMalloc(reinterpret_cast<void**>(&o->scratch), 2 * RED_BLOCKS * sizeof(double)) != hipSuccess) r = NST_E_NOMEM;
     if (r == NST_OK && kind == NST_OPT_ADAM) {
@@ -386,6 +478,11 @@ void nst_opt_destroy(nst_opt* o) {
     for (float* p : ptrs) if (p) (void)hipFree(p);
     if (o->scratch) (void)hipFree(o->scratch);
     if (o->pinned) (void)hipHostFree(o->pinned);
+    if (o->pin2) (void)hipHostFree(o->pin2);
+    if (o->vec_dev) (void)hipFree(o->vec_dev);
+    if (o->md_scratch) (void)hipFree(o->md_scratch);
+    if (o->coef_dev) (void)hipFree(o->coef_dev);
+    if (o->md_out) (void)hipFree(o->md_out);
     for (float* p : o->old_dirs) (void)hipFree(p);
     for (float* p : o->old_stps) (void)hipFree(p);
     for (float* p : o->spare) (void)hipFree(p);

@@ -164,6 +164,119 @@ hipError_t launch_lbfgs_pair(const double* sin, float ro, float* al, int second,
     return hipGetLastError();
 }
 
+// ---- L-BFGS direction from inner products (default; NST_LBFGS_GRAM=0 = the pair kernel above): every history vector is read once for all the
+// dot products the recursion needs of it, and once more for the direction ----------------------------------------
+// Workgroup b owns the float4 indices [1024 b, 1024 b + 1024): its slices of the three operand vectors stay in
+// registers while it walks the history; per history vector it leaves three double partials.
+constexpr int MD_F4 = 4;
+__global__ __launch_bounds__(256) void multi_dot_kernel(const float* const* __restrict__ vecs, int nvec,
+                                                        const float* __restrict__ a, const float* __restrict__ b,
+                                                        const float* __restrict__ c, size_t n, double* __restrict__ scratch) {
+    __shared__ double sh[4][3];
+    const size_t n4 = n / 4;
+    const size_t base = (size_t)blockIdx.x * (256 * MD_F4) + threadIdx.x;
+    f32x4 ra[MD_F4], rb[MD_F4], rc[MD_F4];
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < MD_F4; ++k) {
+        const size_t i = base + (size_t)k * 256;
+        const bool ok = i < n4;
+        ra[k] = ok ? reinterpret_cast<const f32x4*>(a)[i] : z;
+        rb[k] = ok ? reinterpret_cast<const f32x4*>(b)[i] : z;
+        rc[k] = ok ? reinterpret_cast<const f32x4*>(c)[i] : z;
+    }
+    const bool tail = (blockIdx.x == 0 && threadIdx.x == 0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = 0; j < nvec; ++j) {
+        const float* __restrict__ v = vecs[j];
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < MD_F4; ++k) {
+            const size_t i = base + (size_t)k * 256;
+            const f32x4 x = (i < n4) ? reinterpret_cast<const f32x4*>(v)[i] : z;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s0 += x[e] * ra[k][e]; s1 += x[e] * rb[k][e]; s2 += x[e] * rc[k][e]; }
+        }
+        double d0 = s0, d1 = s1, d2 = s2;
+        if (tail)
+            for (size_t i = n4 * 4; i < n; ++i) {
+                d0 += (double)v[i] * (double)a[i]; d1 += (double)v[i] * (double)b[i]; d2 += (double)v[i] * (double)c[i];
+            }
+        for (int off = 32; off > 0; off >>= 1) {
+            d0 += __shfl_down(d0, off, 64); d1 += __shfl_down(d1, off, 64); d2 += __shfl_down(d2, off, 64);
+        }
+        if (lane == 0) { sh[wave][0] = d0; sh[wave][1] = d1; sh[wave][2] = d2; }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int t = threadIdx.x;
+            scratch[((size_t)blockIdx.x * nvec + j) * 3 + t] = ((sh[0][t] + sh[1][t]) + sh[2][t]) + sh[3][t];
+        }
+        __syncthreads();
+    }
+}
+// out[j*3 + t] = sum over the workgroups' partials, in workgroup order
+__global__ __launch_bounds__(256) void multi_dot_finish_kernel(const double* __restrict__ scratch, int blocks, int nvec,
+                                                               float* __restrict__ out) {
+    __shared__ double sh[4];
+    const int o = blockIdx.x;               // = j * 3 + t
+    double s = 0.0;
+    for (int b = threadIdx.x; b < blocks; b += 256) s += scratch[(size_t)b * nvec * 3 + o];
+    const double r = vblock_sum(s, sh);
+    if (threadIdx.x == 0) out[o] = (float)r;
+}
+int multi_dot_blocks(size_t n) { return (int)((n / 4 + 256 * MD_F4 - 1) / (256 * MD_F4)) > 0 ? (int)((n / 4 + 256 * MD_F4 - 1) / (256 * MD_F4)) : 1; }
+hipError_t launch_multi_dot(const float* const* vecs_dev, int nvec, const float* a, const float* b, const float* c, size_t n,
+                            double* scratch, float* out, hipStream_t stream) {
+    const int blocks = multi_dot_blocks(n);
+    hipLaunchKernelGGL(multi_dot_kernel, dim3(blocks), dim3(256), 0, stream, vecs_dev, nvec, a, b, c, n, scratch);
+    hipLaunchKernelGGL(multi_dot_finish_kernel, dim3(nvec * 3), dim3(256), 0, stream, scratch, blocks, nvec, out);
+    return hipGetLastError();
+}
+// d = h * q0 + sum_j coef[j] * vecs[j]  (terms added in the order j = 0, 1, ...)
+__global__ __launch_bounds__(256) void multi_axpy_kernel(const float* const* __restrict__ vecs, const float* __restrict__ coef,
+                                                         int nvec, const float* __restrict__ q0, float h, float* __restrict__ d,
+                                                         size_t n) {
+    const size_t n4 = n / 4;
+    const size_t base = (size_t)blockIdx.x * (256 * MD_F4) + threadIdx.x;
+    f32x4 acc[MD_F4];
+#pragma unroll
+    for (int k = 0; k < MD_F4; ++k) {
+        const size_t i = base + (size_t)k * 256;
+        const f32x4 q = (i < n4) ? reinterpret_cast<const f32x4*>(q0)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[k] = q * h;
+    }
+    const bool tail = (blockIdx.x == 0 && threadIdx.x == 0);
+    float tacc[3] = {0.f, 0.f, 0.f};
+    if (tail)
+        for (size_t i = n4 * 4; i < n; ++i) tacc[i - n4 * 4] = h * q0[i];
+    for (int j = 0; j < nvec; ++j) {
+        const float cj = coef[j];
+        const float* __restrict__ v = vecs[j];
+#pragma unroll
+        for (int k = 0; k < MD_F4; ++k) {
+            const size_t i = base + (size_t)k * 256;
+            if (i < n4) {
+                const f32x4 x = reinterpret_cast<const f32x4*>(v)[i];
+                acc[k] = acc[k] + x * cj;
+            }
+        }
+        if (tail)
+            for (size_t i = n4 * 4; i < n; ++i) tacc[i - n4 * 4] += cj * v[i];
+    }
+#pragma unroll
+    for (int k = 0; k < MD_F4; ++k) {
+        const size_t i = base + (size_t)k * 256;
+        if (i < n4) reinterpret_cast<f32x4*>(d)[i] = acc[k];
+    }
+    if (tail)
+        for (size_t i = n4 * 4; i < n; ++i) d[i] = tacc[i - n4 * 4];
+}
+hipError_t launch_multi_axpy(const float* const* vecs_dev, const float* coef_dev, int nvec, const float* q0, float h, float* d,
+                             size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(multi_axpy_kernel, dim3(multi_dot_blocks(n)), dim3(256), 0, stream, vecs_dev, coef_dev, nvec, q0, h, d, n);
+    return hipGetLastError();
+}
+
 // ---- max|a| and sum|a| ----------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void abs_partial_kernel(const float* __restrict__ a, size_t n,
                                                           double* __restrict__ scratch) {

@@ -496,13 +496,17 @@ def test_lbfgs_trajectory_vs_reference(eng, vgg_weights, golden, tag, max_eval):
     opt.close()
 
 
+@pytest.mark.parametrize("gram", ["1", "0"])
 @pytest.mark.parametrize("h,w", [(35, 51), (64, 96)])
-def test_lbfgs_update_arithmetic_teacher_forced(eng, vgg_weights, h, w):
+def test_lbfgs_update_arithmetic_teacher_forced(eng, vgg_weights, monkeypatch, h, w, gram):
     """The optimiser arithmetic alone - two-loop recursion on the device (one fused launch per history pair), line
     search, curvature pairs - against the oracle's L-BFGS driven by the SAME closure (the HIP one), so that only
     the update arithmetic can differ: 25-evaluation line search, lr 1, so that steps are accepted and the history
-    grows.  35 x 51 gives n = 5355 (n mod 4 = 3: the scalar tails of the vector kernels)."""
+    grows.  35 x 51 gives n = 5355 (n mod 4 = 3: the scalar tails of the vector kernels).  gram = "1": the default
+    direction from inner products (one multi-dot and one multi-axpy pass over the history); "0": the sequential
+    recursion, one fused launch per pair."""
     from artstyletransfer_amd.engine import PixelOptimizer
+    monkeypatch.setenv("NST_LBFGS_GRAM", gram)
     c, s = _levels(h, w, 1, 1), _levels(h, w, 1, 2)
     _setup(eng, c, s)
     x0 = cpu_ref.prepare_img((0.6 * c[0] + 0.4 * s[0]).astype(np.float32)).contiguous()
