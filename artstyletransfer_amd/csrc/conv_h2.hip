@@ -406,6 +406,11 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         }
         __syncthreads();
         request(F[0], ldsA + tap_off(0), ldsB, 0);
+        // Two waves per SIMD: the later-dispatched half of an 8-wave workgroup (waves 4-7) loses issue arbitration to the
+        // older half at the start of every stage.  One s_setprio for that half, once, before the loop (the condition
+        // must be provably wave-uniform: s_setprio ignores EXEC): conv launches -2 % (A/B on one box); flipping the
+        // priority around every MFMA cluster instead gave nothing.
+        if (C::NT == 512 && __builtin_amdgcn_readfirstlane(threadIdx.x) >= 256) __builtin_amdgcn_s_setprio(1);
 
         // one chunk = 9 stages; PAR = which fragment set holds the operands of its first k-step (alternates per
         // stage when a stage is a single k-step, so chunks are then processed in pairs)
