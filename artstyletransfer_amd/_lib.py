@@ -25,9 +25,20 @@ REDUCE_HOOK = C.CFUNCTYPE(None, C.c_void_p)
 c_void = C.c_void_p
 
 
+NST_CONV_F32, NST_CONV_BF16X3, NST_CONV_F16X2 = 0, 1, 2
+CONV_MODES = {"f32": NST_CONV_F32, "bf16x3": NST_CONV_BF16X3, "f16x2": NST_CONV_F16X2}
+NST_COMM_ID_BYTES = 128
+
+
 class StepInfo(C.Structure):
     _fields_ = [("closures", C.c_int), ("total_closures", C.c_int), ("accepted", C.c_int),
-                ("loss", C.c_float), ("lr", C.c_float), ("t", C.c_float)]
+                ("loss", C.c_float), ("lr", C.c_float), ("t", C.c_float), ("history", C.c_int)]
+
+
+class Options(C.Structure):
+    """nst_options: -1 = take the environment variable (read once at context creation), else the default."""
+    _fields_ = [("struct_size", C.c_int), ("conv_mode", C.c_int), ("batched", C.c_int), ("single_stream", C.c_int),
+                ("use_graph", C.c_int), ("h2_band_rows", C.c_int), ("lbfgs_gram", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/nst_hip.h declares
@@ -36,18 +47,31 @@ SYMBOLS = {
     "nst_last_error": (C.c_char_p, [c_void]),
     "nst_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "nst_ctx_create": (C.c_int, [C.c_int, C.POINTER(c_void), C.POINTER(c_void), C.POINTER(c_void)]),
+    "nst_options_default": (None, [C.POINTER(Options)]),
+    "nst_ctx_create_ex": (C.c_int, [C.c_int, C.POINTER(c_void), C.POINTER(c_void), C.POINTER(Options), C.POINTER(c_void)]),
     "nst_ctx_destroy": (None, [c_void]),
     "nst_job_configure": (C.c_int, [c_void, C.c_int, C.c_int, C.c_int]),
     "nst_level_set_targets": (C.c_int, [c_void, C.c_int, c_void, c_void, C.c_int, C.c_int, c_void]),
     "nst_closure": (C.c_int, [c_void, c_void, C.c_float, C.c_float, C.c_float, c_void, c_void, c_void]),
     "nst_closure_levels": (C.c_int, [c_void, c_void, C.c_float, C.c_float, C.c_float, C.c_uint, c_void, c_void, c_void]),
     "nst_opt_shard_levels": (C.c_int, [c_void, C.c_uint, c_void, c_void, c_void, c_void]),
+    "nst_opt_shard_levels_comm": (C.c_int, [c_void, C.c_uint, c_void]),
+    "nst_opt_history": (C.c_int, [c_void, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "nst_comm_unique_id": (C.c_int, [c_void]),
+    "nst_comm_create": (C.c_int, [C.c_int, C.c_int, C.c_int, c_void, C.POINTER(c_void)]),
+    "nst_comm_destroy": (None, [c_void]),
+    "nst_comm_info": (C.c_int, [c_void, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_long), C.POINTER(C.c_double)]),
+    "nst_comm_allreduce_sum": (C.c_int, [c_void, c_void, C.c_size_t, c_void]),
+    "nst_adam_step": (C.c_int, [c_void, c_void, c_void, c_void, c_void, C.c_size_t, C.c_int, C.c_double, c_void]),
+    "nst_lbfgs_direction": (C.c_int, [c_void, c_void, C.POINTER(c_void), C.POINTER(c_void), C.POINTER(C.c_float), C.c_int,
+                                      C.c_float, C.c_size_t, C.c_int, c_void, c_void]),
     "nst_opt_create": (C.c_int, [c_void, C.c_int, C.c_float, C.c_int, C.POINTER(c_void)]),
     "nst_opt_destroy": (None, [c_void]),
     "nst_opt_step": (C.c_int, [c_void, c_void, C.c_float, C.c_float, C.c_float, c_void, C.c_int,
                                C.POINTER(StepInfo), c_void]),
     "nst_vgg_features": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.POINTER(c_void), c_void]),
     "nst_vgg_features_backward": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.POINTER(c_void), c_void, c_void]),
+    "nst_level_activation": (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void]),
     "nst_gram": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, c_void]),
     "nst_total_variation": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void]),
     "nst_bicubic_half": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void]),

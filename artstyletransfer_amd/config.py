@@ -22,9 +22,17 @@ _DEFAULTS = dict(
 
 
 class Config:
-    """Settings of one style-transfer job; keyword arguments as in the reference."""
+    """Settings of one style-transfer job; positional or keyword arguments in the reference's order
+    (config.py:5-18): Config(1e3, 4e5, 1e2, 'adam') and Config(optimizer='adam') both work."""
 
-    def __init__(self, **kwargs):
+    def __init__(self, *args, **kwargs):
+        names = list(_DEFAULTS)
+        if len(args) > len(names):
+            raise TypeError(f"Config() takes at most {len(names)} positional arguments ({len(args)} given)")
+        for name, value in zip(names, args):
+            if name in kwargs:
+                raise TypeError(f"Config() got multiple values for argument '{name}'")
+            kwargs[name] = value
         unknown = set(kwargs) - set(_DEFAULTS)
         if unknown:
             raise TypeError(f"Config() got unexpected keyword argument(s): {sorted(unknown)}")

@@ -884,9 +884,8 @@ hipError_t launch_conv_h2(const ConvParams& p0, hipStream_t stream) {
         band_rows = (int)(fit / 16) * 16;
         if (band_rows < 16) return hipErrorInvalidValue;
     }
-    // test hook: NST_H2_BAND_ROWS=<rows> forces bands on small images, so the parity tests walk the band arithmetic
-    const char* fb = std::getenv("NST_H2_BAND_ROWS");          // (read per launch: tests switch it inside one process)
-    const int forced_band = fb ? std::atoi(fb) : 0;
+    // test hook (nst_options.h2_band_rows): forces bands on small images, so the parity tests walk the band arithmetic
+    const int forced_band = p.band_rows;
     if (forced_band >= 16 && forced_band / 16 * 16 < band_rows) band_rows = forced_band / 16 * 16;
     const int PW2 = p.W >> 1, wi = p.Cin >> 5, wo = p.Cout >> 5;
     for (int r0 = 0; r0 < p.H; r0 += band_rows) {

@@ -99,6 +99,10 @@ struct nst_ctx {
     // 3x3 convs: 2 = fp16 pipe, 2 scaled pieces per operand (3 MFMAs per product block; default),
     //            1 = bf16 pipe, 3 exact pieces (6 MFMAs), 0 = fp32 MFMA
     int conv_mode = 2;
+    int band_rows = 0;          // nst_options.h2_band_rows (0 = bands only for tensors beyond 4 GiB)
+    int lbfgs_gram = 1;         // nst_options.lbfgs_gram
+    hipEvent_t tail = nullptr;  // recorded after the last launch that touches context-owned memory: what
+                                // nst_job_configure / nst_ctx_destroy wait for instead of the whole device
     int batched = 1;            // 1: one conv launch per layer covering every pyramid level (one stream)
     // hipGraph of the closure: captured the second time the same (buffers, weights, mask) are seen
     int use_graph = 0;          // measured: no gain (the host already runs ~16 ms ahead of the GPU); NST_GRAPH=1 enables
@@ -344,6 +348,7 @@ int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s
             p.wt_h2 = ctx->wf_h2[l]; p.wt_h2_inv = ctx->wf_h2_inv[l];
             p.amax_in = amax_act(a, l - 1);       // the pooled map's maximum is its source's
             p.amax_out = amax_act(a, l);
+            p.band_rows = ctx->band_rows;
         }
         const int pa = pool_index_after(l);
         const bool fuse = bf3_unsplit(ctx, p);        // the epilogue extras exist in the unsplit bf3 kernel only
@@ -417,6 +422,7 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
             p.wt_h2 = ctx->wd_h2[l]; p.wt_h2_inv = ctx->wd_h2_inv[l];
             p.amax_in = amax_grad(a, l);
             p.amax_out = amax_grad(a, l - 1);     // when un-pooled next, this bounds the un-pooled gradient too
+            p.band_rows = ctx->band_rows;
         }
         if (pk >= 0) {
             {
@@ -766,12 +772,32 @@ int bind(nst_ctx* ctx) {
     return NST_OK;
 }
 
+// Remember where the context's work ends: an event on the caller's stream after the last launch of an entry point that
+// reads or writes context-owned memory.
+void mark(nst_ctx* ctx, hipStream_t s) {
+    if (ctx && ctx->tail) (void)hipEventRecord(ctx->tail, s);
+}
+// Wait until nothing on the device uses the context's memory any more: its tail event and its own streams - NOT
+// hipDeviceSynchronize, which would stall the other job sharing the GPU (two jobs per GPU is the scheduler's default).
+void quiesce(nst_ctx* ctx) {
+    if (ctx->tail) (void)hipEventSynchronize(ctx->tail);
+    for (int i = 0; i < NST_MAX_LEVELS; ++i)
+        if (ctx->lv[i].stream) (void)hipStreamSynchronize(ctx->lv[i].stream);
+    if (ctx->gstream) (void)hipStreamSynchronize(ctx->gstream);
+}
+
+int env_flag(const char* name, int dflt) {
+    const char* e = getenv(name);
+    if (!e || !e[0]) return dflt;
+    return std::atoi(e);
+}
+
 }  // namespace
 
 // ================================================================================================
 extern "C" {
 
-int nst_version(void) { return 100; }
+int nst_version(void) { return 200; }
 
 const char* nst_last_error(const nst_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
@@ -784,8 +810,25 @@ int nst_device_count(int* count) {
     return NST_OK;
 }
 
+void nst_options_default(nst_options* o) {
+    if (!o) return;
+    o->struct_size = (int)sizeof(nst_options);
+    o->conv_mode = -1; o->batched = -1; o->single_stream = -1; o->use_graph = -1; o->h2_band_rows = -1; o->lbfgs_gram = -1;
+}
+
 int nst_ctx_create(int device, const float* const* weights, const float* const* biases, nst_ctx** out) {
+    return nst_ctx_create_ex(device, weights, biases, nullptr, out);
+}
+
+int nst_ctx_create_ex(int device, const float* const* weights, const float* const* biases, const nst_options* opts_in,
+                      nst_ctx** out) {
     if (!weights || !biases || !out) return fail(nullptr, NST_E_ARG, "null argument");
+    nst_options opts;
+    nst_options_default(&opts);
+    if (opts_in) {
+        if (opts_in->struct_size != (int)sizeof(nst_options)) return fail(nullptr, NST_E_ARG, "nst_options.struct_size mismatch (use nst_options_default)");
+        opts = *opts_in;
+    }
     for (int l = 0; l < NL; ++l)
         if (!weights[l] || !biases[l]) return fail(nullptr, NST_E_ARG, "null weight/bias pointer");
     int ndev = 0;
@@ -800,19 +843,24 @@ int nst_ctx_create(int device, const float* const* weights, const float* const* 
     if (e == hipSuccess) e = conv_bf3_init_device();
     if (e == hipSuccess) e = conv_h2_init_device();
     if (e == hipSuccess) e = gram_init_device();
-    const char* cm = getenv("NST_CONV");
-    if (cm && std::strcmp(cm, "f32") == 0) ctx->conv_mode = 0;
-    else if (cm && std::strcmp(cm, "bf16x3") == 0) ctx->conv_mode = 1;
-    else if (cm && std::strcmp(cm, "f16x2") == 0) ctx->conv_mode = 2;
-    else if (cm && cm[0]) { ctx->err = "NST_CONV must be f32, bf16x3 or f16x2"; return bail(NST_E_ARG); }
-    const char* bm = getenv("NST_BATCH");
-    if (bm && bm[0] == '0') ctx->batched = 0;
-    const char* gm = getenv("NST_GRAPH");
-    if (gm && gm[0] == '1') ctx->use_graph = 1;
-    if (hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "stream creation failed"; return bail(NST_E_HIP); }
+    // options: an explicit argument wins; -1 falls back to the environment (read here, once), then to the default
+    if (opts.conv_mode >= 0) {
+        if (opts.conv_mode > NST_CONV_F16X2) { ctx->err = "nst_options.conv_mode must be NST_CONV_F32, NST_CONV_BF16X3 or NST_CONV_F16X2"; return bail(NST_E_ARG); }
+        ctx->conv_mode = opts.conv_mode;
+    } else {
+        const char* cm = getenv("NST_CONV");
+        if (cm && std::strcmp(cm, "f32") == 0) ctx->conv_mode = 0;
+        else if (cm && std::strcmp(cm, "bf16x3") == 0) ctx->conv_mode = 1;
+        else if (cm && std::strcmp(cm, "f16x2") == 0) ctx->conv_mode = 2;
+        else if (cm && cm[0]) { ctx->err = "NST_CONV must be f32, bf16x3 or f16x2"; return bail(NST_E_ARG); }
+    }
+    ctx->batched = (opts.batched >= 0 ? opts.batched : env_flag("NST_BATCH", 1)) ? 1 : 0;
+    ctx->use_graph = (opts.use_graph >= 0 ? opts.use_graph : env_flag("NST_GRAPH", 0)) ? 1 : 0;
+    ctx->single_stream = (opts.single_stream >= 0 ? opts.single_stream : env_flag("NST_SINGLE_STREAM", 0)) != 0;
+    ctx->band_rows = opts.h2_band_rows >= 0 ? opts.h2_band_rows : env_flag("NST_H2_BAND_ROWS", 0);
+    ctx->lbfgs_gram = (opts.lbfgs_gram >= 0 ? opts.lbfgs_gram : env_flag("NST_LBFGS_GRAM", 1)) ? 1 : 0;
+    if (ctx->use_graph && hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "stream creation failed"; return bail(NST_E_HIP); }
     if (e != hipSuccess) { ctx->err = std::string("kernel attribute setup: ") + hipGetErrorString(e); return bail(NST_E_HIP); }
-    const char* ss = getenv("NST_SINGLE_STREAM");
-    ctx->single_stream = ss && ss[0] == '1';
 
     std::vector<float> tmp;
     std::vector<uint16_t> tmp16;
@@ -875,6 +923,7 @@ int nst_ctx_create(int device, const float* const* weights, const float* const* 
         }
     }
     if (hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->tail, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
         ctx->err = "event creation failed";
         return bail(NST_E_HIP);
@@ -886,8 +935,9 @@ int nst_ctx_create(int device, const float* const* weights, const float* const* 
 void nst_ctx_destroy(nst_ctx* ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    (void)hipDeviceSynchronize();
+    quiesce(ctx);
     for (int i = 0; i < NST_MAX_LEVELS; ++i) free_level(ctx, ctx->lv[i]);
+    if (ctx->tail) (void)hipEventDestroy(ctx->tail);
     for (int l = 0; l < NL; ++l) { dev_free(ctx->wf[l]); dev_free(ctx->wd[l]); dev_free(ctx->bias[l]); dev_free(ctx->wf_bf[l]); dev_free(ctx->wd_bf[l]); dev_free(ctx->wf_h2[l]); dev_free(ctx->wd_h2[l]); }
     dev_free(ctx->w11k); dev_free(ctx->w11d);
     if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
@@ -912,7 +962,7 @@ int nst_job_configure(nst_ctx* ctx, int levels_num, int H0, int W0) {
     if (levels_num < 1 || levels_num > NST_MAX_LEVELS) return fail(ctx, NST_E_ARG, "levels_num out of range");
     if ((H0 >> (levels_num - 1)) < 16 || (W0 >> (levels_num - 1)) < 16)
         return fail(ctx, NST_E_ARG, "coarsest pyramid level must be at least 16x16");
-    HIPCHK(ctx, hipDeviceSynchronize());
+    quiesce(ctx);
     for (int i = 0; i < NST_MAX_LEVELS; ++i) free_level(ctx, ctx->lv[i]);
     if (ctx->gexec) { (void)hipGraphExecDestroy(ctx->gexec); ctx->gexec = nullptr; }
     ctx->gkey = {}; ctx->glast = {};
@@ -943,8 +993,6 @@ int nst_job_configure(nst_ctx* ctx, int levels_num, int H0, int W0) {
         NSTCHK(dev_alloc_t(ctx, &L.content_partial, MSE_BLOCKS));
         NSTCHK(dev_alloc_t(ctx, &L.tv_partial, 2 * TV_BLOCKS));
         NSTCHK(dev_alloc_t(ctx, &L.tv_means, 2));
-        HIPCHK(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-        HIPCHK(ctx, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
         h /= 2; w /= 2;
     }
     ctx->levels = levels_num;
@@ -1054,6 +1102,7 @@ int nst_closure_levels(nst_ctx* ctx, const float* x, float cw, float sw, float t
     }
     if (!done) NSTCHK(closure_record(ctx, x, cw, sw, tvw, level_mask, grad, losses, main));
     if (ctx->timing) { HIPCHK(ctx, hipEventRecord(ctx->t1, main)); ctx->timed_valid = true; }
+    mark(ctx, main);
     return NST_OK;
 }
 
@@ -1075,7 +1124,15 @@ static int closure_record(nst_ctx* ctx, const float* x, float cw, float sw, floa
         NSTCHK(closure_batched(ctx, xi, gi, level_mask, cw, sw, tvw, main));
     }
     const bool multi = !batch && !ctx->single_stream && ctx->levels > 1;
-    if (multi) HIPCHK(ctx, hipEventRecord(ctx->fork, main));
+    if (multi) {
+        // the per-level streams exist only for this schedule (a stream costs device memory that HIP does not hand back)
+        for (int i = 0; i < ctx->levels; ++i) {
+            LevelWs& L = ctx->lv[i];
+            if (!L.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+            if (!L.done) HIPCHK(ctx, hipEventCreateWithFlags(&L.done, hipEventDisableTiming));
+        }
+        HIPCHK(ctx, hipEventRecord(ctx->fork, main));
+    }
 
     for (int i = 0; i < ctx->levels && !batch; ++i) {
         LevelWs& L = ctx->lv[i];
@@ -1192,6 +1249,7 @@ int nst_window_begin(nst_ctx* ctx, const float* xs, int row0, int rows, int H0, 
     // total variation: sums of |dx|, |dy| over the owned rows (batched_forward ran the windowed partial pass)
     HIPCHK(ctx, launch_sum_doubles(L.tv_partial, TV_BLOCKS, 2, 0, sums + kWinScalarOff + 1, s));
     HIPCHK(ctx, launch_sum_doubles(L.tv_partial, TV_BLOCKS, 2, 1, sums + kWinScalarOff + 2, s));
+    mark(ctx, s);
     return NST_OK;
 }
 
@@ -1228,6 +1286,7 @@ int nst_window_end(nst_ctx* ctx, const float* xs, int row0, int rows, int H0, fl
     la.lv[0].tv_means = L.tv_means;
     la.lv[0].owned = 1;
     HIPCHK(ctx, launch_loss_assemble(la, s));
+    mark(ctx, s);
     return NST_OK;
 }
 
@@ -1307,6 +1366,17 @@ int nst_vgg_features(nst_ctx* ctx, const float* x, int h, int w, float* const* o
     free_acts(ctx, a);
     if (r != NST_OK) return r;
     HIPCHK(ctx, e);
+    return NST_OK;
+}
+
+int nst_level_activation(nst_ctx* ctx, int level, int layer, float* out, void* stream) {
+    NSTCHK(bind(ctx));
+    if (level < 0 || level >= ctx->levels) return fail(ctx, NST_E_STATE, "level not configured");
+    if (layer < 0 || layer >= NL || !out) return fail(ctx, NST_E_ARG, "bad argument");
+    const ActSet& a = ctx->lv[level].acts;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIPCHK(ctx, launch_hwc_to_chw(a.act[layer], kCout[layer], a.h[layer], a.w[layer], out, s));
+    mark(ctx, s);
     return NST_OK;
 }
 
@@ -1467,5 +1537,7 @@ int nst_internal_device(const nst_ctx* ctx) { return ctx ? ctx->device : 0; }
 int nst_internal_levels(const nst_ctx* ctx) { return ctx ? ctx->levels : 0; }
 size_t nst_internal_pixels(const nst_ctx* ctx) { return (ctx && ctx->levels > 0) ? (size_t)ctx->lv[0].h * ctx->lv[0].w : 0; }
 int nst_internal_fail(nst_ctx* ctx, int code, const char* msg) { return fail(ctx, code, msg ? msg : ""); }
+int nst_internal_lbfgs_gram(const nst_ctx* ctx) { return ctx ? ctx->lbfgs_gram : 1; }
+void nst_internal_mark(nst_ctx* ctx, void* stream) { mark(ctx, static_cast<hipStream_t>(stream)); }
 
 }  // extern "C"

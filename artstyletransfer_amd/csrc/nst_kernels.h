@@ -45,6 +45,7 @@ struct ConvParams {
     unsigned* pcode_out;
     int in2_row0, in2_rows;    // in2_rows > 0: the second source contributes on output rows [in2_row0, in2_row0 + in2_rows) only
     int ty0;                   // first tile row of this launch (filled by the launcher: tensors from 4 GiB up run in row bands)
+    int band_rows;             // conv_h2: >= 16 forces row bands of that many rows (nst_options.h2_band_rows; 0 = only when needed)
 };
 
 constexpr int NST_AMAX_SLOTS = 64;
@@ -244,7 +245,7 @@ hipError_t launch_add_scaled(const float* a, float alpha, const float* b, float*
 hipError_t launch_zero(void* out, size_t n_words, hipStream_t stream);                                      // out[0..n) = 0 (32-bit words, 16-byte aligned)
 hipError_t launch_copy(const float* a, float* out, size_t n, hipStream_t stream);                          // out = a (16-byte aligned)
 hipError_t launch_sub(const float* a, const float* b, float* out, size_t n, hipStream_t stream);           // out = a-b
-hipError_t launch_adam(float* x, const float* g, float* m, float* v, size_t n, float beta1, float beta2, float eps,
-                       float step_size, float inv_sqrt_bc2, hipStream_t stream);
+hipError_t launch_adam(float* x, const float* g, float* m, float* v, size_t n, float beta2, float one_m_b1, float one_m_b2,
+                       float eps, float step_size, float bc2_sqrt, hipStream_t stream);
 
 }  // namespace nst

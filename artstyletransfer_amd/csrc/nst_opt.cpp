@@ -23,6 +23,8 @@ extern "C" int nst_internal_device(const nst_ctx* ctx);
 extern "C" int nst_internal_levels(const nst_ctx* ctx);
 extern "C" size_t nst_internal_pixels(const nst_ctx* ctx);
 extern "C" int nst_internal_fail(nst_ctx* ctx, int code, const char* msg);
+extern "C" int nst_internal_lbfgs_gram(const nst_ctx* ctx);
+extern "C" void nst_internal_mark(nst_ctx* ctx, void* stream);
 
 struct nst_opt {
     nst_ctx* ctx = nullptr;
@@ -58,7 +60,10 @@ struct nst_opt {
     float* d = nullptr; float* prev_g = nullptr; float* xinit = nullptr; float* q = nullptr;
     std::vector<float*> old_dirs, old_stps;
     std::vector<float> ro;
-    std::vector<float*> spare;   // recycled history vectors
+    std::vector<float*> spare;   // free history vectors: slices of `pool`
+    float* pool = nullptr;       // ONE allocation made by nst_opt_create holding every history vector (2*history + 2
+                                 // of them): no hipMalloc - an implicit device synchronisation - inside a step
+    hipEvent_t tail = nullptr;   // recorded after the last launch of every step: what nst_opt_destroy waits for
     bool H_is_one = true; float H_diag = 1.f;
     bool t_is_float = true;      // t held as fp32 tensor value vs python double
     double t = 0.0;
@@ -68,6 +73,9 @@ struct nst_opt {
     nst_reduce_hook hook = nullptr;
     void* hook_user = nullptr;
     float* own_g = nullptr; float* own_losses = nullptr;   // buffers this object allocated
+    nst_comm* comm = nullptr;    // RCCL communicator (nst_opt_shard_levels_comm): all-reduce of `pack` per closure
+    float* pack = nullptr;       // gradient (n floats, padded to 64) followed by the loss row: ONE collective buffer
+    size_t pack_floats = 0;
     // per-step outputs
     std::vector<float> loss_rows;   // host copy of every closure's loss rows in this step
 };
@@ -105,7 +113,8 @@ int eval_closure(nst_opt* o, const float* x, float cw, float sw, float tvw, hipS
                  GradStats* gs = nullptr) {
     o->lr *= 0.999;                                                          // neural_style_transfer.py:155-158
     OCHK(nst_closure_levels(o->ctx, x, cw, sw, tvw, o->level_mask, o->g, o->losses, s));
-    if (o->hook) o->hook(o->hook_user);                                      // all-reduce(sum) over the ranks
+    if (o->comm) OCHK(nst_comm_allreduce_sum(o->comm, o->pack, o->pack_floats, s));   // gradient + loss row, one call
+    else if (o->hook) o->hook(o->hook_user);                                 // all-reduce(sum) over the ranks
     const size_t row = (size_t)NST_LOSS_ROW * o->levels + 1;
     const size_t off = o->loss_rows.size();
     o->loss_rows.resize(off + row);
@@ -116,6 +125,14 @@ int eval_closure(nst_opt* o, const float* x, float cw, float sw, float tvw, hipS
     if (gs && gs->dot_with) OHIP(o, launch_dot(o->g, gs->dot_with, o->n, o->scratch, o->scal + 2, s));
     if (gs) OHIP(o, hipMemcpyAsync(r, o->scal, 3 * sizeof(float), hipMemcpyDeviceToHost, s));
     OHIP(o, hipStreamSynchronize(s));
+    if (o->comm) {
+        // every level row has exactly one non-zero contributor, so the rows are exact; the grand total is re-formed from
+        // them in level order - the association of the unsharded closure (neural_style_transfer.py:179-185) - so that
+        // L-BFGS' `f_new < f` takes the same branch as the unsharded run
+        float total = hrow[0];
+        for (int l = 1; l < o->levels; ++l) total = total + hrow[(size_t)NST_LOSS_ROW * l];
+        hrow[row - 1] = total;
+    }
     std::memcpy(o->loss_rows.data() + off, hrow, row * sizeof(float));
     if (gs) { gs->gmax = r[0]; gs->gsum = r[1]; gs->gdot = r[2]; }
     o->total_closures += 1;                                                  // :198
@@ -263,6 +280,25 @@ int strong_wolfe(nst_opt* o, float* x, double t, float f, float gtd, float d_nor
     return NST_OK;
 }
 
+// the two recurrences of the inner-product form below on host scalars: coef[j] multiplies y_j, coef[m + j] multiplies s_j
+void direction_coefficients(int m, int ld, const double* SYm, const double* YYm, const float* ro, float Hd,
+                            const double* sq, const double* yq, float* coef) {
+    std::vector<double> al(m), be(m);
+    for (int i = m - 1; i >= 0; --i) {
+        double v = sq[i];                                             // s_i . q0
+        for (int j = i + 1; j < m; ++j) v -= al[j] * SYm[(size_t)i * ld + j];
+        al[i] = (double)ro[i] * v;
+    }
+    for (int i = 0; i < m; ++i) {
+        double t = yq[i];                                             // y_i . q0
+        for (int j = 0; j < m; ++j) t -= al[j] * YYm[(size_t)j * ld + i];
+        double v = (double)Hd * t;
+        for (int j = 0; j < i; ++j) v += (al[j] - be[j]) * SYm[(size_t)j * ld + i];
+        be[i] = (double)ro[i] * v;
+    }
+    for (int j = 0; j < m; ++j) { coef[j] = (float)(-(double)Hd * al[j]); coef[m + j] = (float)(al[j] - be[j]); }
+}
+
 // d = -H g by the two-loop recursion (lbfgs.py:444-460) carried out on inner products: with q0 = -g,
 //   al_i = ro_i (s_i.q0 - sum_{j>i} al_j s_i.y_j)                                   (first loop, i = m-1 .. 0)
 //   be_i = ro_i (H (y_i.q0 - sum_j al_j y_j.y_i) + sum_{j<i} (al_j - be_j) s_j.y_i)  (second loop, i = 0 .. m-1)
@@ -297,20 +333,9 @@ int gram_direction(nst_opt* o, bool new_pair, hipStream_t s) {
             SY(j, k) = hres[(size_t)(m + j) * 3 + 1];                 // s_j . y_k
         }
     }
-    std::vector<double> al(m), be(m);
-    for (int i = m - 1; i >= 0; --i) {
-        double v = hres[(size_t)(m + i) * 3 + 2];                     // s_i . q0
-        for (int j = i + 1; j < m; ++j) v -= al[j] * SY(i, j);
-        al[i] = (double)o->ro[i] * v;
-    }
-    for (int i = 0; i < m; ++i) {
-        double yq = hres[(size_t)i * 3 + 2];                          // y_i . q0
-        for (int j = 0; j < m; ++j) yq -= al[j] * YY(j, i);
-        double v = (double)Hd * yq;
-        for (int j = 0; j < i; ++j) v += (al[j] - be[j]) * SY(j, i);
-        be[i] = (double)o->ro[i] * v;
-    }
-    for (int j = 0; j < m; ++j) { hcoef[j] = (float)(-(double)Hd * al[j]); hcoef[m + j] = (float)(al[j] - be[j]); }
+    std::vector<double> sq(m), yq(m);
+    for (int i = 0; i < m; ++i) { sq[i] = hres[(size_t)(m + i) * 3 + 2]; yq[i] = hres[(size_t)i * 3 + 2]; }
+    direction_coefficients(m, Hh, o->SY.data(), o->YY.data(), o->ro.data(), Hd, sq.data(), yq.data(), hcoef);
     OHIP(o, hipMemcpyAsync(o->coef_dev, hcoef, 2 * (size_t)m * sizeof(float), hipMemcpyHostToDevice, s));
     OHIP(o, launch_multi_axpy(o->vec_dev, o->coef_dev, 2 * m, o->q, Hd, o->d, o->n, s));
     return NST_OK;
@@ -337,8 +362,9 @@ int lbfgs_step(nst_opt* o, float* x, float cw, float sw, float tvw, hipStream_t 
         // y = g - prev_g ; s = d * t
         float* y; float* st;
         auto take = [&](float** p) -> int {
-            if (!o->spare.empty()) { *p = o->spare.back(); o->spare.pop_back(); return NST_OK; }
-            return oalloc(o, p, o->n);
+            if (o->spare.empty()) return nst_internal_fail(o->ctx, NST_E_STATE, "L-BFGS history pool exhausted");
+            *p = o->spare.back(); o->spare.pop_back();
+            return NST_OK;
         };
         OCHK(take(&y)); OCHK(take(&st));
         OHIP(o, launch_sub(o->g, o->prev_g, y, o->n, s));
@@ -434,13 +460,20 @@ int nst_opt_create(nst_ctx* ctx, int kind, float lr_start, int lbfgs_max_eval, n
     o->levels = nst_internal_levels(ctx);
     o->n = 3 * nst_internal_pixels(ctx);
     o->max_eval = lbfgs_max_eval < 1 ? 1 : lbfgs_max_eval;
-    int r = oalloc(o, &o->g, o->n);
-    if (r == NST_OK) r = oalloc(o, &o->losses, (size_t)NST_LOSS_ROW * o->levels + 1);
-    o->own_g = o->g; o->own_losses = o->losses;
+    const size_t row = (size_t)NST_LOSS_ROW * o->levels + 1;
+    // gradient and loss row live in ONE allocation (gradient padded to 64 floats): the sharded closure all-reduces both
+    // with a single collective (nst_opt_shard_levels_comm)
+    const size_t n_pad = (o->n + 63) & ~(size_t)63;
+    o->pack_floats = n_pad + row;
+    int r = oalloc(o, &o->pack, o->pack_floats);
+    if (r == NST_OK && hipMemset(o->pack, 0, o->pack_floats * sizeof(float)) != hipSuccess) r = NST_E_HIP;
+    o->g = o->own_g = o->pack;
+    o->losses = o->own_losses = o->pack ? o->pack + n_pad : nullptr;
     if (r == NST_OK) r = oalloc(o, &o->scal, 4);
+    if (r == NST_OK && hipEventCreateWithFlags(&o->tail, hipEventDisableTiming) != hipSuccess) r = NST_E_HIP;
     if (r == NST_OK && kind == NST_OPT_LBFGS) r = oalloc(o, &o->al_dev, (size_t)o->history);
-    const char* gm = std::getenv("NST_LBFGS_GRAM");      // "0": the sequential recursion, one fused launch per pair and loop
-    if (r == NST_OK && kind == NST_OPT_LBFGS && !(gm && gm[0] == '0')) {
+    // nst_options.lbfgs_gram (env NST_LBFGS_GRAM as the default): 0 = the sequential recursion, one fused launch per pair and loop
+    if (r == NST_OK && kind == NST_OPT_LBFGS && nst_internal_lbfgs_gram(ctx)) {
         const size_t H2 = 2 * (size_t)o->history;
         o->gram_mode = true;
         o->SY.assign((size_t)o->history * o->history, 0.0);
@@ -464,6 +497,14 @@ int nst_opt_create(nst_ctx* ctx, int kind, float lr_start, int lbfgs_max_eval, n
         if (r == NST_OK) r = oalloc(o, &o->prev_g, o->n);
         if (r == NST_OK) r = oalloc(o, &o->xinit, o->n);
         if (r == NST_OK) r = oalloc(o, &o->q, o->n);
+        // the whole curvature history up front: history pairs (y, s) + the pair being formed.  3.8 GB at L=2, 15 GB at
+        // L=3 of the 288 GB; a job that cannot have it fails here, not in the middle of its run
+        const size_t nvec = 2 * (size_t)o->history + 2;
+        if (r == NST_OK) r = oalloc(o, &o->pool, nvec * n_pad);
+        if (r == NST_OK) {
+            o->spare.reserve(nvec);
+            for (size_t i = nvec; i-- > 0;) o->spare.push_back(o->pool + i * n_pad);
+        }
     }
     if (r != NST_OK) { nst_opt_destroy(o); return nst_internal_fail(ctx, r, "optimiser allocation failed"); }
     *out = o;
@@ -473,8 +514,10 @@ int nst_opt_create(nst_ctx* ctx, int kind, float lr_start, int lbfgs_max_eval, n
 void nst_opt_destroy(nst_opt* o) {
     if (!o) return;
     (void)hipSetDevice(nst_internal_device(o->ctx));
-    (void)hipDeviceSynchronize();
-    float* ptrs[] = {o->own_g, o->own_losses, o->scal, o->al_dev, o->m, o->v, o->d, o->prev_g, o->xinit, o->q};
+    // wait for THIS optimiser's last launches only (a device-wide synchronisation would stall the other job that
+    // shares the GPU in the two-jobs-per-GPU serving mode)
+    if (o->tail) { (void)hipEventSynchronize(o->tail); (void)hipEventDestroy(o->tail); }
+    float* ptrs[] = {o->pack, o->scal, o->al_dev, o->m, o->v, o->d, o->prev_g, o->xinit, o->q, o->pool};
     for (float* p : ptrs) if (p) (void)hipFree(p);
     if (o->scratch) (void)hipFree(o->scratch);
     if (o->pinned) (void)hipHostFree(o->pinned);
@@ -483,9 +526,6 @@ void nst_opt_destroy(nst_opt* o) {
     if (o->md_scratch) (void)hipFree(o->md_scratch);
     if (o->coef_dev) (void)hipFree(o->coef_dev);
     if (o->md_out) (void)hipFree(o->md_out);
-    for (float* p : o->old_dirs) (void)hipFree(p);
-    for (float* p : o->old_stps) (void)hipFree(p);
-    for (float* p : o->spare) (void)hipFree(p);
     delete o;
 }
 
@@ -495,9 +535,118 @@ int nst_opt_shard_levels(nst_opt* o, unsigned level_mask, float* grad, float* lo
         return nst_internal_fail(o->ctx, NST_E_ARG, "a reduce hook needs caller-owned grad and losses buffers (and vice versa)");
     o->level_mask = level_mask;
     o->hook = hook; o->hook_user = user;
+    o->comm = nullptr;
     o->g = grad ? grad : o->own_g;
     o->losses = losses ? losses : o->own_losses;
     return NST_OK;
+}
+
+int nst_opt_shard_levels_comm(nst_opt* o, unsigned level_mask, nst_comm* comm) {
+    if (!o) return nst_internal_fail(nullptr, NST_E_ARG, "null optimiser");
+    o->level_mask = comm ? level_mask : 0xFFFFFFFFu;
+    o->hook = nullptr; o->hook_user = nullptr;
+    o->comm = comm;
+    o->g = o->own_g; o->losses = o->own_losses;
+    return NST_OK;
+}
+
+int nst_opt_history(const nst_opt* o, int* pairs, int* n_iter) {
+    if (!o) return nst_internal_fail(nullptr, NST_E_ARG, "null optimiser");
+    if (pairs) *pairs = (int)o->old_dirs.size();
+    if (n_iter) *n_iter = o->kind == NST_OPT_ADAM ? o->k : o->n_iter;
+    return NST_OK;
+}
+
+// torch:optim/adam.py:457-546 for one tensor, step count k (1-based), group lr `lr` (a python double in the reference)
+static int adam_update(nst_ctx* ctx, float* x, const float* g, float* m, float* v, size_t n, int k, double lr, hipStream_t s,
+                       float* step_size_out) {
+    const double bc1 = 1.0 - std::pow(0.9, k);
+    const double bc2 = 1.0 - std::pow(0.999, k);
+    const double step_size = lr / bc1;
+    // 1 - beta as torch forms them: double differences, rounded to fp32 when they meet the fp32 tensors
+    const hipError_t e = launch_adam(x, g, m, v, n, 0.999f, (float)(1.0 - 0.9), (float)(1.0 - 0.999), 1e-8f, (float)step_size,
+                                     (float)std::sqrt(bc2), s);
+    if (e != hipSuccess) return nst_internal_fail(ctx, NST_E_HIP, hipGetErrorString(e));
+    if (step_size_out) *step_size_out = (float)step_size;
+    return NST_OK;
+}
+
+int nst_adam_step(nst_ctx* ctx, float* x, const float* g, float* m, float* v, size_t n, int k, double lr, void* stream) {
+    if (!ctx || !x || !g || !m || !v || k < 1) return nst_internal_fail(ctx, NST_E_ARG, "bad argument");
+    if (hipSetDevice(nst_internal_device(ctx)) != hipSuccess) return nst_internal_fail(ctx, NST_E_HIP, "hipSetDevice failed");
+    return adam_update(ctx, x, g, m, v, n, k, lr, static_cast<hipStream_t>(stream), nullptr);
+}
+
+int nst_lbfgs_direction(nst_ctx* ctx, const float* g, const float* const* y, const float* const* sv, const float* ro, int m,
+                        float h_diag, size_t n, int form, float* d, void* stream) {
+    if (!ctx || !g || !d || m < 0 || (m > 0 && (!y || !sv || !ro)) || (form != 0 && form != 1))
+        return nst_internal_fail(ctx, NST_E_ARG, "bad argument");
+    if (hipSetDevice(nst_internal_device(ctx)) != hipSuccess) return nst_internal_fail(ctx, NST_E_HIP, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    nst_opt tmp;                       // only for the error macros
+    tmp.ctx = ctx;
+    nst_opt* o = &tmp;
+    float* q = nullptr; float* al_dev = nullptr; float* coef_dev = nullptr; float* md_out = nullptr;
+    double* scratch = nullptr; double* md_scratch = nullptr; const float** vec_dev = nullptr;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(s);
+        for (void* p : {(void*)q, (void*)al_dev, (void*)coef_dev, (void*)md_out, (void*)scratch, (void*)md_scratch, (void*)vec_dev})
+            if (p) (void)hipFree(p);
+    };
+    auto body = [&]() -> int {
+        OHIP(o, hipMalloc(reinterpret_cast<void**>(&q), n * sizeof(float)));
+        OHIP(o, launch_scale_copy(-1.f, g, q, n, s));                               // q0 = -g
+        if (m == 0) { OHIP(o, launch_scale_copy(h_diag, q, d, n, s)); return NST_OK; }
+        if (form == 1) {
+            // sequential form: the arithmetic order of torch's two loops, one fused launch per pair and loop
+            OHIP(o, hipMalloc(reinterpret_cast<void**>(&al_dev), (size_t)m * sizeof(float)));
+            OHIP(o, hipMalloc(reinterpret_cast<void**>(&scratch), 2 * RED_BLOCKS * sizeof(double)));
+            double* pp[2] = {scratch, scratch + RED_BLOCKS};
+            int cur = 0;
+            OHIP(o, launch_dot_partial(sv[m - 1], q, n, pp[cur], s));
+            for (int i = m - 1; i >= 0; --i) {
+                OHIP(o, launch_lbfgs_pair(pp[cur], ro[i], al_dev + i, 0, y[i], q, i > 0 ? sv[i - 1] : nullptr, n, pp[cur ^ 1], s));
+                cur ^= 1;
+            }
+            OHIP(o, launch_scale_copy(h_diag, q, d, n, s));
+            OHIP(o, launch_dot_partial(y[0], d, n, pp[cur], s));
+            for (int i = 0; i < m; ++i) {
+                OHIP(o, launch_lbfgs_pair(pp[cur], ro[i], al_dev + i, 1, sv[i], d, i + 1 < m ? y[i + 1] : nullptr, n, pp[cur ^ 1], s));
+                cur ^= 1;
+            }
+            return NST_OK;
+        }
+        // inner-product form: S^T Y and Y^T Y by m multi-dot passes (the optimiser driver keeps them incrementally, one
+        // pass per step), then the same recurrences and the same multi-axpy pass as the driver
+        const size_t M2 = 2 * (size_t)m;
+        OHIP(o, hipMalloc(reinterpret_cast<void**>(&vec_dev), M2 * sizeof(float*)));
+        OHIP(o, hipMalloc(reinterpret_cast<void**>(&md_scratch), (size_t)multi_dot_blocks(n) * M2 * 3 * sizeof(double)));
+        OHIP(o, hipMalloc(reinterpret_cast<void**>(&md_out), M2 * 3 * sizeof(float)));
+        OHIP(o, hipMalloc(reinterpret_cast<void**>(&coef_dev), M2 * sizeof(float)));
+        std::vector<const float*> hp(M2);
+        for (int j = 0; j < m; ++j) { hp[j] = y[j]; hp[m + j] = sv[j]; }
+        OHIP(o, hipMemcpyAsync(vec_dev, hp.data(), M2 * sizeof(float*), hipMemcpyHostToDevice, s));
+        std::vector<double> SY((size_t)m * m), YY((size_t)m * m), sq(m), yq(m);
+        std::vector<float> res(M2 * 3), coef(M2);
+        for (int k = 0; k < m; ++k) {
+            OHIP(o, launch_multi_dot(vec_dev, (int)M2, sv[k], y[k], q, n, md_scratch, md_out, s));
+            OHIP(o, hipMemcpyAsync(res.data(), md_out, M2 * 3 * sizeof(float), hipMemcpyDeviceToHost, s));
+            OHIP(o, hipStreamSynchronize(s));
+            for (int j = 0; j < m; ++j) {
+                SY[(size_t)k * m + j] = res[(size_t)j * 3 + 0];            // s_k . y_j
+                YY[(size_t)k * m + j] = res[(size_t)j * 3 + 1];            // y_k . y_j
+            }
+            if (k == 0) for (int j = 0; j < m; ++j) { yq[j] = res[(size_t)j * 3 + 2]; sq[j] = res[(size_t)(m + j) * 3 + 2]; }
+        }
+        direction_coefficients(m, m, SY.data(), YY.data(), ro, h_diag, sq.data(), yq.data(), coef.data());
+        OHIP(o, hipMemcpyAsync(coef_dev, coef.data(), M2 * sizeof(float), hipMemcpyHostToDevice, s));
+        OHIP(o, launch_multi_axpy(vec_dev, coef_dev, (int)M2, q, h_diag, d, n, s));
+        OHIP(o, hipStreamSynchronize(s));      // `coef` is pageable host memory: keep it alive until the copy has run
+        return NST_OK;
+    };
+    const int rc = body();
+    cleanup();
+    return rc;
 }
 
 int nst_opt_step(nst_opt* o, float* x, float cw, float sw, float tvw, float* losses_host, int closures_capacity,
@@ -515,21 +664,22 @@ int nst_opt_step(nst_opt* o, float* x, float cw, float sw, float tvw, float* los
         } else {
             o->lr *= 0.999;
             OCHK(nst_closure_levels(o->ctx, x, cw, sw, tvw, o->level_mask, o->g, o->losses, s));
-            if (o->hook) o->hook(o->hook_user);
+            if (o->comm) OCHK(nst_comm_allreduce_sum(o->comm, o->pack, o->pack_floats, s));
+            else if (o->hook) o->hook(o->hook_user);
             o->total_closures += 1;
         }
         o->k += 1;
-        const double bc1 = 1.0 - std::pow(0.9, o->k);
-        const double bc2 = 1.0 - std::pow(0.999, o->k);
-        const double step_size = o->lr / bc1;                    // lr already decayed by the closure
-        OHIP(o, launch_adam(x, o->g, o->m, o->v, o->n, 0.9f, 0.999f, 1e-8f, (float)step_size, (float)std::sqrt(bc2), s));
-        info->loss = loss; info->accepted = 1; info->t = (float)step_size;
+        float step_size = 0.f;
+        OCHK(adam_update(o->ctx, x, o->g, o->m, o->v, o->n, o->k, o->lr, s, &step_size));   // lr already decayed by the closure
+        info->loss = loss; info->accepted = 1; info->t = step_size;
     } else {
         OCHK(lbfgs_step(o, x, cw, sw, tvw, s, info));
     }
+    OHIP(o, hipEventRecord(o->tail, s));
     info->closures = o->total_closures - before;
     info->total_closures = o->total_closures;
     info->lr = (float)o->lr;
+    info->history = (int)o->old_dirs.size();
     if (losses_host) {
         const size_t row = (size_t)NST_LOSS_ROW * o->levels + 1;
         const size_t have = o->loss_rows.size() / row;

@@ -391,26 +391,28 @@ hipError_t launch_sub(const float* a, const float* b, float* out, size_t n, hipS
 }
 
 // ---- Adam (single tensor, no amsgrad / weight decay) -----------------------------------------------
+// torch's CPU kernels round like this (checked bit for bit against torch 2.10 on 2^20 random elements): lerp_ is
+// fma(w, g - m, m); addcmul_ is fma((1-b2) g, g, v b2); the denominator is a true division plus eps; addcdiv_ is
+// x + (value * m) / denom.  w and 1-b2 arrive as floats rounded from the DOUBLE differences 1 - 0.9 and 1 - 0.999
+// (0.1f and 0.001f), which is what torch passes - 1.f - 0.999f is 1.3e-5 off.
 __global__ void adam_kernel(float* __restrict__ x, const float* __restrict__ g, float* __restrict__ m,
-                            float* __restrict__ v, size_t n, float beta1, float beta2, float eps, float step_size,
-                            float bc2_sqrt) {
-    const float w = 1.f - beta1;
-    const float one_m_b2 = 1.f - beta2;
+                            float* __restrict__ v, size_t n, float beta2, float one_m_b1, float one_m_b2, float eps,
+                            float neg_step_size, float bc2_sqrt) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const float gi = g[i];
         float mi = m[i], vi = v[i];
-        mi = mi + w * (gi - mi);                                    // exp_avg.lerp_(grad, 1 - beta1)
-        vi = __fmul_rn(vi, beta2) + one_m_b2 * gi * gi;             // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        const float denom = __fdiv_rn(__fsqrt_rn(vi), bc2_sqrt) + eps;
-        x[i] = x[i] - step_size * __fdiv_rn(mi, denom);             // addcdiv_(exp_avg, denom, value=-step_size)
+        mi = __fmaf_rn(one_m_b1, __fsub_rn(gi, mi), mi);                         // exp_avg.lerp_(grad, 1 - beta1)
+        vi = __fmaf_rn(__fmul_rn(one_m_b2, gi), gi, __fmul_rn(vi, beta2));       // mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), bc2_sqrt), eps);
+        x[i] = __fadd_rn(x[i], __fdiv_rn(__fmul_rn(neg_step_size, mi), denom));  // addcdiv_(exp_avg, denom, value=-step_size)
         m[i] = mi;
         v[i] = vi;
     }
 }
-hipError_t launch_adam(float* x, const float* g, float* m, float* v, size_t n, float beta1, float beta2, float eps,
-                       float step_size, float bc2_sqrt, hipStream_t stream) {
-    hipLaunchKernelGGL(adam_kernel, dim3(vblocks(n)), dim3(256), 0, stream, x, g, m, v, n, beta1, beta2, eps, step_size,
-                       bc2_sqrt);
+hipError_t launch_adam(float* x, const float* g, float* m, float* v, size_t n, float beta2, float one_m_b1, float one_m_b2,
+                       float eps, float step_size, float bc2_sqrt, hipStream_t stream) {
+    hipLaunchKernelGGL(adam_kernel, dim3(vblocks(n)), dim3(256), 0, stream, x, g, m, v, n, beta2, one_m_b1, one_m_b2, eps,
+                       -step_size, bc2_sqrt);
     return hipGetLastError();
 }
 

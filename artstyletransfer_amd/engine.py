@@ -35,7 +35,11 @@ def _chk_dev(t: torch.Tensor, device, shape=None):
 class StyleEngine:
     """One nst_ctx: VGG19 weights on one GPU + the pyramid workspace of one job."""
 
-    def __init__(self, weights: Sequence[Tuple[torch.Tensor, torch.Tensor]], device: int | str | torch.device = 0):
+    def __init__(self, weights: Sequence[Tuple[torch.Tensor, torch.Tensor]], device: int | str | torch.device = 0,
+                 conv_mode: Optional[str] = None, batched: Optional[bool] = None, single_stream: Optional[bool] = None,
+                 use_graph: Optional[bool] = None, h2_band_rows: Optional[int] = None, lbfgs_gram: Optional[bool] = None):
+        """Options (nst_options): None = environment variable (NST_CONV, NST_BATCH, NST_SINGLE_STREAM, NST_GRAPH,
+        NST_H2_BAND_ROWS, NST_LBFGS_GRAM; read once, here) and otherwise the default (f16x2, batched, ...)."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise NstError("no GPU visible: the style-transfer hot path runs only on the HIP device")
@@ -50,8 +54,18 @@ class StyleEngine:
         bs = [np.ascontiguousarray(b.detach().cpu().numpy(), dtype=np.float32) for _, b in weights]
         wp = (C.c_void_p * 13)(*[a.ctypes.data for a in ws])
         bp = (C.c_void_p * 13)(*[a.ctypes.data for a in bs])
+        opts = _lib.Options()
+        self.lib.nst_options_default(C.byref(opts))
+        if conv_mode is not None:
+            if conv_mode not in _lib.CONV_MODES:
+                raise NstError(f"conv_mode must be one of {sorted(_lib.CONV_MODES)}")
+            opts.conv_mode = _lib.CONV_MODES[conv_mode]
+        for name, val in (("batched", batched), ("single_stream", single_stream), ("use_graph", use_graph),
+                          ("h2_band_rows", h2_band_rows), ("lbfgs_gram", lbfgs_gram)):
+            if val is not None:
+                setattr(opts, name, int(val))
         ctx = C.c_void_p()
-        _lib.check(None, self.lib.nst_ctx_create(idx, wp, bp, C.byref(ctx)), "nst_ctx_create")
+        _lib.check(None, self.lib.nst_ctx_create_ex(idx, wp, bp, C.byref(opts), C.byref(ctx)), "nst_ctx_create_ex")
         self.ctx = ctx
         self.levels = 0
         self.shape = None
@@ -143,8 +157,35 @@ class StyleEngine:
                                                      _ptr(losses), _stream(self.device)), "nst_window_end")
         return gxs, losses
 
+    # ---- the optimisers' update arithmetic alone (unit parity) -------------------------------------------
+    def adam_step(self, x: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, k: int, lr: float) -> None:
+        """One torch.optim.Adam update in place (nst_adam_step): x, m, v from g at step count k with group lr."""
+        for t in (x, g, m, v):
+            _chk_dev(t, self.device)
+            if t.numel() != x.numel():
+                raise NstError("x, g, m, v must have the same number of elements")
+        _lib.check(self.ctx, self.lib.nst_adam_step(self.ctx, _ptr(x), _ptr(g), _ptr(m), _ptr(v), x.numel(), k, float(lr),
+                                                    _stream(self.device)), "nst_adam_step")
+
+    def lbfgs_direction(self, g: torch.Tensor, ys: Sequence[torch.Tensor], ss: Sequence[torch.Tensor], ro: Sequence[float],
+                        h_diag: float, form: int = 0) -> torch.Tensor:
+        """d = -H g from the curvature pairs (nst_lbfgs_direction); form 0 = inner products, 1 = sequential recursion."""
+        _chk_dev(g, self.device)
+        m = len(ys)
+        for t in list(ys) + list(ss):
+            _chk_dev(t, self.device)
+            if t.numel() != g.numel():
+                raise NstError("history vectors must have g's size")
+        yp = (C.c_void_p * max(m, 1))(*[t.data_ptr() for t in ys])
+        sp = (C.c_void_p * max(m, 1))(*[t.data_ptr() for t in ss])
+        rp = (C.c_float * max(m, 1))(*[float(r) for r in ro])
+        d = torch.empty_like(g)
+        _lib.check(self.ctx, self.lib.nst_lbfgs_direction(self.ctx, _ptr(g), yp, sp, rp, m, float(h_diag), g.numel(), form,
+                                                          _ptr(d), _stream(self.device)), "nst_lbfgs_direction")
+        return d
+
     def conv_mode(self) -> str:
-        """How the 3x3 convolutions are evaluated (env NST_CONV at context creation): 'f16x2' (default: two scaled
+        """How the 3x3 convolutions are evaluated (nst_options.conv_mode; env NST_CONV by default): 'f16x2' (default: two scaled
         fp16 pieces per fp32 operand, 3 MFMAs per product block, fp32 accumulate), 'bf16x3' (three exact bf16
         pieces, 6 MFMAs) or 'f32' (fp32 MFMA)."""
         return {0: "f32", 1: "bf16x3", 2: "f16x2"}[self.lib.nst_conv_mode(self.ctx)]
@@ -200,6 +241,21 @@ class StyleEngine:
         _lib.check(self.ctx, self.lib.nst_vgg_features_backward(self.ctx, _ptr(x), h, w, arr, _ptr(gx),
                                                                 _stream(self.device)), "nst_vgg_features_backward")
         return gx
+
+    LAYER_CHANNELS = (64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512)
+    LAYER_SCALE = (0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4)
+
+    def level_activations(self, level: int) -> List[torch.Tensor]:
+        """The 13 post-ReLU conv outputs the last closure left in the workspace of `level` (nst_level_activation),
+        each (1,C,h,w): what the parity tests derive the device pass's ReLU / pooling decisions from."""
+        h, w = self.level_shape(level)
+        outs = []
+        for l, (c, sc) in enumerate(zip(self.LAYER_CHANNELS, self.LAYER_SCALE)):
+            t = torch.empty((1, c, h >> sc, w >> sc), dtype=torch.float32, device=self.device)
+            _lib.check(self.ctx, self.lib.nst_level_activation(self.ctx, level, l, _ptr(t), _stream(self.device)),
+                       "nst_level_activation")
+            outs.append(t)
+        return outs
 
     def gram(self, f: torch.Tensor, normalize: bool = True) -> torch.Tensor:
         _chk_dev(f, self.device)
@@ -317,6 +373,21 @@ class PixelOptimizer:
         self.cap = 32 if name == "lbfgs" else 1
         self._rows = np.zeros((self.cap, self.row), dtype=np.float32)
 
+    def shard_levels_comm(self, comm: "Communicator") -> None:
+        """Level sharding with the collective behind the C ABI (nst_opt_shard_levels_comm): one ncclAllReduce of the packed
+        gradient + loss row per closure on the job's stream, no Python in the loop."""
+        from . import sharding
+        e = self.engine
+        self._comm = comm
+        _lib.check(e.ctx, e.lib.nst_opt_shard_levels_comm(self.h, sharding.level_mask(e.levels, comm.rank, comm.world),
+                                                          comm.h), "nst_opt_shard_levels_comm")
+
+    def history(self):
+        """(curvature pairs held, optimiser iteration count)."""
+        p, n = C.c_int(), C.c_int()
+        _lib.check(self.engine.ctx, self.engine.lib.nst_opt_history(self.h, C.byref(p), C.byref(n)), "nst_opt_history")
+        return p.value, n.value
+
     def shard_levels(self, rank: int, world: int, dist_mod=None, group=None) -> None:
         """Level sharding (BASELINE config 4): this rank evaluates only its levels; after every closure
         the partial gradient and loss rows are all-reduced (RCCL) before the driver reads them."""
@@ -390,6 +461,50 @@ class PixelOptimizer:
         if getattr(self, "h", None) and getattr(self.engine, "ctx", None):
             self.engine.lib.nst_opt_destroy(self.h)
         self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Communicator:
+    """nst_comm: an RCCL communicator behind the C ABI (one rank per GPU).  `id_bytes`: the NST_COMM_ID_BYTES of
+    `Communicator.unique_id()` made on rank 0 and handed to every rank (e.g. with torch.distributed.broadcast_object_list
+    over gloo, or a file)."""
+
+    def __init__(self, device: int, rank: int, world: int, id_bytes: bytes):
+        self.lib = _lib.load()
+        if len(id_bytes) != _lib.NST_COMM_ID_BYTES:
+            raise NstError("communicator id must be NST_COMM_ID_BYTES long")
+        buf = C.create_string_buffer(bytes(id_bytes), _lib.NST_COMM_ID_BYTES)
+        h = C.c_void_p()
+        _lib.check(None, self.lib.nst_comm_create(int(device), rank, world, buf, C.byref(h)), "nst_comm_create")
+        self.h, self.rank, self.world, self.device = h, rank, world, torch.device("cuda", int(device))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        lib = _lib.load()
+        buf = C.create_string_buffer(_lib.NST_COMM_ID_BYTES)
+        _lib.check(None, lib.nst_comm_unique_id(buf), "nst_comm_unique_id")
+        return buf.raw
+
+    def allreduce_sum(self, t: torch.Tensor) -> None:
+        _chk_dev(t, self.device)
+        _lib.check(None, self.lib.nst_comm_allreduce_sum(self.h, _ptr(t), t.numel(), _stream(self.device)),
+                   "nst_comm_allreduce_sum")
+
+    def info(self):
+        """(rank, world, all-reduce calls so far, bytes carried)."""
+        r, w, n, b = C.c_int(), C.c_int(), C.c_long(), C.c_double()
+        _lib.check(None, self.lib.nst_comm_info(self.h, C.byref(r), C.byref(w), C.byref(n), C.byref(b)), "nst_comm_info")
+        return r.value, w.value, n.value, b.value
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.nst_comm_destroy(self.h)
+            self.h = None
 
     def __del__(self):
         try:

@@ -3,11 +3,15 @@
 `Vgg19` keeps the reference's attributes (`layer_names`, `content_feature_maps_index`,
 `style_feature_maps_indices`) and returns the same `VggOutputs` namedtuple, but holds no
 torch modules: the 13 frozen conv layers live, re-laid-out, inside a `StyleEngine` per GPU.
-Pretrained weights cannot be downloaded offline (neural_nets.py:19 fetches them): point
-NST_VGG19_WEIGHTS at a local torchvision `vgg19` state-dict file, otherwise seeded synthetic
-weights are used and a warning is printed."""
+The reference downloads torchvision's pretrained checkpoint into TORCH_HOME = its own directory
+(neural_nets.py:19, neural_style_transfer.py:8-10).  Here the file is only ever read from disk:
+NST_VGG19_WEIGHTS (a path), else `$TORCH_HOME/hub/checkpoints/vgg19-*.pth`, else the same under the
+directory of the drop-in modules and under ~/.cache/torch.  Without a file `load_weights` RAISES - a
+switched-over deployment must not silently paint with random weights - unless NST_SYNTHETIC_WEIGHTS=1
+opts into the seeded synthetic set (benchmarks, demos without a checkpoint)."""
 from __future__ import annotations
 
+import glob
 import os
 import threading
 import warnings
@@ -25,18 +29,53 @@ _engines: Dict[int, StyleEngine] = {}
 _lock = threading.Lock()
 
 
+def state_dict_to_weights(sd) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+    """torchvision vgg19 state dict -> the 13 (weight, bias) pairs conv1_1..conv5_1 (features.0 ... features.28)."""
+    ws = []
+    for i, (cin, cout) in zip(_FEATURE_CONV_INDICES, synthetic.VGG19_CONV_SHAPES):
+        try:
+            w, b = sd[f"features.{i}.weight"], sd[f"features.{i}.bias"]
+        except KeyError as e:
+            raise KeyError(f"not a torchvision vgg19 state dict: {e} is missing") from e
+        if tuple(w.shape) != (cout, cin, 3, 3) or tuple(b.shape) != (cout,):
+            raise ValueError(f"features.{i}: expected weight {(cout, cin, 3, 3)} and bias {(cout,)}, got "
+                             f"{tuple(w.shape)} and {tuple(b.shape)}")
+        ws.append((w.detach().float().contiguous(), b.detach().float().contiguous()))
+    return ws
+
+
+def find_checkpoint() -> str | None:
+    """The pretrained file where the reference's download would have put it (never fetched here)."""
+    explicit = os.environ.get("NST_VGG19_WEIGHTS")
+    if explicit:
+        return explicit
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # directory of the drop-in modules
+    homes = [os.environ.get("TORCH_HOME"), root, os.path.join(os.path.expanduser("~"), ".cache", "torch")]
+    for home in homes:
+        if not home:
+            continue
+        hits = sorted(glob.glob(os.path.join(home, "hub", "checkpoints", "vgg19-*.pth")))
+        if hits:
+            return hits[0]
+    return None
+
+
 def load_weights() -> List[Tuple[torch.Tensor, torch.Tensor]]:
     global _weights_cache
     if _weights_cache is not None:
         return _weights_cache
-    path = os.environ.get("NST_VGG19_WEIGHTS")
+    path = find_checkpoint()
     if path:
-        sd = torch.load(path, map_location="cpu")
-        ws = [(sd[f"features.{i}.weight"].float(), sd[f"features.{i}.bias"].float()) for i in _FEATURE_CONV_INDICES]
-    else:
-        warnings.warn("NST_VGG19_WEIGHTS is not set: using seeded synthetic VGG19 weights "
+        ws = state_dict_to_weights(torch.load(path, map_location="cpu"))
+    elif os.environ.get("NST_SYNTHETIC_WEIGHTS") == "1":
+        warnings.warn("NST_SYNTHETIC_WEIGHTS=1: using seeded synthetic VGG19 weights "
                       "(results are not artistically meaningful)")
         ws = synthetic.vgg19_weights()
+    else:
+        raise FileNotFoundError(
+            "no VGG19 checkpoint found: set NST_VGG19_WEIGHTS to a torchvision vgg19 state-dict file, or put "
+            "vgg19-*.pth under $TORCH_HOME/hub/checkpoints (where the reference's download caches it); "
+            "NST_SYNTHETIC_WEIGHTS=1 opts into seeded synthetic weights (benchmarks only)")
     _weights_cache = ws
     return ws
 

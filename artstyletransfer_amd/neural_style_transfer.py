@@ -9,6 +9,7 @@ There is no CPU path: without a GPU and the built extension these entry points r
 from __future__ import annotations
 
 import asyncio
+import os
 import traceback
 from typing import List, Optional
 
@@ -24,8 +25,9 @@ IMAGENET_MEAN_255 = [123.675, 116.28, 103.53]
 IMAGENET_STD_NEUTRAL = [1, 1, 1]
 
 # how many closure evaluations LBFGS may spend per step; 1 = torch 2.10 semantics of the reference's
-# constructor arguments, 26 = the line search older torch builds performed
-LBFGS_MAX_EVAL = 1
+# constructor arguments (almost every trial step is rejected), 26 = the line search older torch builds
+# performed.  Environment NST_LBFGS_MAX_EVAL overrides it at import; see INTEGRATION.md.
+LBFGS_MAX_EVAL = int(os.environ.get("NST_LBFGS_MAX_EVAL", "1"))
 VERBOSE = False
 
 
@@ -117,6 +119,7 @@ class NeuralStyleTransfer:
         # it is set around synchronous sections only, never across an await.
         job_stream = torch.cuda.Stream(device=dev)
         job_stream.wait_stream(torch.cuda.current_stream(dev))     # the caller built the input images there
+        optimizer = None
         try:
             def prepared(img):      # numpy HWC (reference) or a device HWC tensor built by device_image
                 if isinstance(img, torch.Tensor):
@@ -178,10 +181,14 @@ class NeuralStyleTransfer:
                 if pending is not None:          # the consumer stopped early: let the running step finish
                     try:
                         await pending
-                    except Exception:
+                    except BaseException:
                         pass
-            optimizer.close()
         finally:
+            # Normal end, a consumer that stops early (aclose / GeneratorExit at the yield), a cancelled task or a
+            # failed step all come through here: the optimiser goes first (its curvature history alone is up to
+            # 200 x 12*H*W bytes), then the engine it was created on.
+            if optimizer is not None:
+                optimizer.close()
             job_stream.synchronize()
             engine.close()
 

@@ -13,12 +13,16 @@ VGG19_CONV_SHAPES = ((3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256,
                      (256, 512), (512, 512), (512, 512), (512, 512), (512, 512))
 
 
-def vgg19_weights(seed: int = 1234) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+def vgg19_weights(seed: int = 1234, bias_std: float = 0.0) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+    """Kaiming fan-out weights, b = 0 (the bench workload).  bias_std > 0 draws seeded biases from a
+    second generator (the parity tests use 2.0: pretrained VGG19 biases are not zero)."""
     g = torch.Generator().manual_seed(seed)
+    gb = torch.Generator().manual_seed(seed + 1)
     out = []
     for cin, cout in VGG19_CONV_SHAPES:
         w = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (cout * 9))
-        out.append((w, torch.zeros(cout)))
+        b = torch.randn(cout, generator=gb) * bias_std if bias_std else torch.zeros(cout)
+        out.append((w, b))
     return out
 
 

@@ -82,7 +82,7 @@ def mfma_roofline(mode, algorithmic_flops, ms, launches, extra=None):
     return out
 
 
-def build_job(levels_num: int, seed_shift: int, device):
+def build_job(levels_num: int, seed_shift: int, device, **engine_options):
     """Synthetic L = levels_num-1 job, set up the way neural_style_transfer() does it: pyramid and structured-noise
     initial image on the device (device_image.py), targets through nst_level_set_targets."""
     from artstyletransfer_amd import device_image, synthetic
@@ -96,7 +96,7 @@ def build_job(levels_num: int, seed_shift: int, device):
     style = synthetic.image(H, W, seed=2 + 2 * seed_shift)
     cfg = Config(levels_num=levels_num)
     weights = synthetic.vgg19_weights()
-    eng = StyleEngine(weights, device)
+    eng = StyleEngine(weights, device, **engine_options)
     t0 = time.perf_counter()
     cd, sd = device_image.upload(eng, content), device_image.upload(eng, style)
     content_levels = device_image.pyramid(eng, cd, levels_num)

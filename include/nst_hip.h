@@ -41,6 +41,7 @@ extern "C" {
 
 typedef struct nst_ctx nst_ctx;
 typedef struct nst_opt nst_opt;
+typedef struct nst_comm nst_comm;
 
 /* library / device ------------------------------------------------------------------------ */
 int nst_version(void);
@@ -54,6 +55,29 @@ int nst_device_count(int* count);
  * keeps device copies re-laid-out for the forward and the input-gradient kernels. */
 int nst_ctx_create(int device, const float* const* weights, const float* const* biases, nst_ctx** out);
 void nst_ctx_destroy(nst_ctx* ctx);
+
+/* The same with the execution options as ARGUMENTS (nst_ctx_create = nst_ctx_create_ex with opts == NULL).  A field
+ * left at -1 takes the environment variable named beside it, read ONCE here, and otherwise the stated default; the
+ * environment is never consulted again during the life of the context.  There is no counterpart in the reference
+ * (torch picks its kernels by itself); the options exist for the parity tests, which hold the alternative
+ * arithmetic / schedules against the default one. */
+#define NST_CONV_F32 0      /* fp32 MFMA (v_mfma_f32_32x32x2_f32): the reference's arithmetic type, exactly */
+#define NST_CONV_BF16X3 1   /* bf16 matrix pipe, three bf16 pieces that sum to the fp32 value exactly, 6 MFMAs */
+#define NST_CONV_F16X2 2    /* fp16 matrix pipe, two scaled fp16 pieces per operand, 3 MFMAs per product block (default) */
+typedef struct nst_options {
+    int struct_size;      /* sizeof(nst_options), filled by nst_options_default */
+    int conv_mode;        /* NST_CONV_*; -1: env NST_CONV (f32 | bf16x3 | f16x2), default f16x2 */
+    int batched;          /* 1: one conv launch per layer covering every pyramid level; 0: per level; -1: env NST_BATCH, default 1 */
+    int single_stream;    /* per-level schedule only - 1: all levels on the caller's stream; -1: env NST_SINGLE_STREAM, default 0 */
+    int use_graph;        /* 1: replay the closure as a hipGraph; -1: env NST_GRAPH, default 0 */
+    int h2_band_rows;     /* >= 16: run the f16x2 per-level launches in row bands of that many rows (the path tensors beyond
+                             4 GiB take, forced onto small images); -1: env NST_H2_BAND_ROWS, default 0 = only when needed */
+    int lbfgs_gram;       /* 1: L-BFGS direction from inner products (two passes over the history); 0: the sequential
+                             recursion; -1: env NST_LBFGS_GRAM, default 1 */
+} nst_options;
+void nst_options_default(nst_options* opts);
+int nst_ctx_create_ex(int device, const float* const* weights, const float* const* biases, const nst_options* opts,
+                      nst_ctx** out);
 
 /* pyramid geometry of one job: levels_num levels, level 0 = (H0, W0), level l = previous // 2
  * (neural_style_transfer.py:170-176).  Allocates the activation workspace of every level. */
@@ -98,6 +122,7 @@ typedef struct nst_step_info {
     float loss;          /* loss of the FIRST closure of this step (what optimizer.step returns) */
     float lr;            /* learning rate after this step's decays */
     float t;             /* L-BFGS step length taken (0 when rejected) */
+    int history;         /* L-BFGS: curvature pairs held after this step (0..100) */
 } nst_step_info;
 
 /* one optimizer.step(closure) (neural_style_transfer.py:205-206).  x: device (3,H0,W0), updated
@@ -116,6 +141,40 @@ typedef void (*nst_reduce_hook)(void* user);
 int nst_opt_shard_levels(nst_opt* opt, unsigned level_mask, float* grad, float* losses, nst_reduce_hook hook,
                          void* user);
 
+/* The same with the collective behind the ABI: every closure the driver evaluates covers `level_mask`, then ONE
+ * ncclAllReduce(sum, fp32) over `comm` of a single buffer holding the 3*H0*W0 gradient floats followed by the
+ * NST_LOSS_ROW*levels+1 loss scalars, on the stream passed to nst_opt_step; the grand total is re-formed from the level rows
+ * in level order, so L-BFGS' accept test takes the same branch as the unsharded run.  comm == NULL switches sharding off. */
+int nst_opt_shard_levels_comm(nst_opt* opt, unsigned level_mask, nst_comm* comm);
+
+/* curvature pairs currently held by L-BFGS and the optimiser's iteration count (Adam: its step count k) */
+int nst_opt_history(const nst_opt* opt, int* pairs, int* n_iter);
+
+/* ---- RCCL communicator (one rank per GPU; the reference has no collective: neural_style_transfer.py:236-245).
+ * librccl is resolved at run time; without it these return NST_E_STATE.  Bootstrap: rank 0 calls nst_comm_unique_id and
+ * hands the NST_COMM_ID_BYTES bytes to the other ranks by whatever channel the host program has (file, socket, MPI,
+ * torch.distributed); then every rank calls nst_comm_create (collective). */
+#define NST_COMM_ID_BYTES 128
+int nst_comm_unique_id(void* id);
+int nst_comm_create(int device, int rank, int world, const void* id, nst_comm** out);
+void nst_comm_destroy(nst_comm* comm);
+/* rank / world of the communicator and what it has carried so far (any pointer may be NULL) */
+int nst_comm_info(const nst_comm* comm, int* rank, int* world, long* calls, double* bytes);
+/* in-place all-reduce(sum) of n floats at the DEVICE pointer buf, ordered on `stream` */
+int nst_comm_allreduce_sum(nst_comm* comm, float* buf, size_t n, void* stream);
+
+/* ---- the optimisers' update arithmetic alone, exported for unit parity -------------------------------
+ * One torch.optim.Adam update (torch:optim/adam.py:457-546, betas (0.9, 0.999), eps 1e-8) of the n floats at x from the
+ * gradient g and the state (m = exp_avg, v = exp_avg_sq), all DEVICE pointers updated in place; k: the step count of
+ * this update (1-based), lr: the group's learning rate at this update (neural_style_transfer.py:134, :155-158). */
+int nst_adam_step(nst_ctx* ctx, float* x, const float* g, float* m, float* v, size_t n, int k, double lr, void* stream);
+/* The L-BFGS direction d = -H g of torch:optim/lbfgs.py:396-442 from m curvature pairs: y[i] = old_dirs[i],
+ * s[i] = old_stps[i] (HOST arrays of m DEVICE pointers, oldest first), ro[i] = 1 / (y_i . s_i) (HOST floats),
+ * h_diag = H_diag; g, d: DEVICE, n floats.  form 0: from inner products (what the driver runs by default), form 1: the
+ * sequential two-loop recursion in torch's arithmetic order.  Synchronous. */
+int nst_lbfgs_direction(nst_ctx* ctx, const float* g, const float* const* y, const float* const* s, const float* ro, int m,
+                        float h_diag, size_t n, int form, float* d, void* stream);
+
 /* ---- standalone pieces of the path, exported for unit parity -------------------------------- */
 
 /* Vgg19.forward (neural_nets.py:53-68): x device (3,h,w) -> the six maps, each written as
@@ -124,6 +183,11 @@ int nst_vgg_features(nst_ctx* ctx, const float* x, int h, int w, float* const* o
 /* d(sum_i <outs_i, gouts_i>)/dx through the network: gouts[i] device (C,h_i,w_i) or NULL. */
 int nst_vgg_features_backward(nst_ctx* ctx, const float* x, int h, int w, const float* const* gouts,
                               float* gx, void* stream);
+/* The post-ReLU output of conv layer `layer` (0 = conv1_1 ... 12 = conv5_1) that the LAST closure / window pass left in the
+ * workspace of pyramid level `level`, written as (C,h_l,w_l) planar fp32 to out (device).  The parity tests read the
+ * ReLU and max-pool DECISIONS of the device pass from it (a unit is on where the value is > 0; a pooling window passes its
+ * gradient to its first maximum) and hand them to the oracle, so that gradients are compared under equal decisions. */
+int nst_level_activation(nst_ctx* ctx, int level, int layer, float* out, void* stream);
 /* math_utils.gram_matrix (math_utils.py:26-34): f device (C,h,w) -> gram device (C,C). */
 int nst_gram(nst_ctx* ctx, const float* f, int C, int h, int w, int normalize, float* gram, void* stream);
 /* math_utils.total_variation (math_utils.py:37-41): value (device scalar) and, if grad != NULL,
@@ -181,11 +245,9 @@ int nst_window_begin(nst_ctx* ctx, const float* xs, int row0, int rows, int H0, 
 int nst_window_end(nst_ctx* ctx, const float* xs, int row0, int rows, int H0, float content_weight, float style_weight,
                    float tv_weight, float* sums, float* gxs, float* losses, void* stream);
 
-/* arithmetic of the 3x3 convolutions (environment NST_CONV at context creation):
- *   2 = "f16x2" (default): fp16 matrix pipe, both operands cut into two scaled fp16 pieces, 3 MFMAs per product
- *       block, main and cross terms in separate fp32 accumulators (error measured against fp64 = an fp32 MFMA's);
- *   1 = "bf16x3": bf16 matrix pipe, three bf16 pieces that sum to the fp32 value exactly, 6 MFMAs;
- *   0 = "f32": fp32 MFMA (v_mfma_f32_32x32x2_f32). */
+/* arithmetic of the 3x3 convolutions of this context (nst_options.conv_mode): NST_CONV_F16X2 (default: both operands
+ * cut into two scaled fp16 pieces, main and cross terms in separate fp32 accumulators; error measured against fp64 =
+ * an fp32 MFMA's), NST_CONV_BF16X3 or NST_CONV_F32. */
 int nst_conv_mode(const nst_ctx* ctx);
 
 /* workspace bytes currently held by the context (activations, gradients, history, targets) */

@@ -51,12 +51,22 @@ STYLE_INDICES = (0, 1, 2, 3, 5)   # neural_nets.py:27-28
 # --------------------------------------------------------------------------
 # synthetic, seeded inputs; mirrored by artstyletransfer_amd.synthetic
 # --------------------------------------------------------------------------
-def synthetic_vgg19_weights(seed: int = 1234) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+# Standard deviation of the seeded conv biases of the weight set the parity tests and the golden fixtures use.
+# SURVEY 8(d) defines the BENCH weights with b = 0; pretrained VGG19 biases are not zero, so every parity test runs
+# with biases that matter (pre-activations under these weights have a standard deviation of 9..22).
+TEST_BIAS_STD = 2.0
+
+
+def synthetic_vgg19_weights(seed: int = 1234, bias_std: float = 0.0) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+    """Kaiming fan-out weights; biases b = bias_std * randn from a generator of their own (seed + 1), so
+    the weight values do not depend on bias_std."""
     g = torch.Generator().manual_seed(seed)
+    gb = torch.Generator().manual_seed(seed + 1)
     out = []
     for _, cin, cout in VGG19_CONVS:
         w = torch.randn(cout, cin, 3, 3, generator=g) * math.sqrt(2.0 / (cout * 9))
-        out.append((w, torch.zeros(cout)))
+        b = torch.randn(cout, generator=gb) * bias_std if bias_std else torch.zeros(cout)
+        out.append((w, b))
     return out
 
 
@@ -105,15 +115,41 @@ def total_variation(y: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------
 # neural_nets.py:53-68 (forward), topology from torchvision cfg "E"
 # --------------------------------------------------------------------------
-def vgg19_features(x: torch.Tensor, weights: Sequence[Tuple[torch.Tensor, torch.Tensor]]):
-    """Returns the 6 maps (relu1_1, relu2_1, relu3_1, relu4_1, ReLU(conv4_2), relu5_1)."""
+class Decisions:
+    """The ReLU and max-pool DECISIONS of another evaluation of the same network - the device pass - read off its 13
+    post-ReLU activation maps: a unit is on where its value is > 0; a pooling window hands its gradient to its first
+    maximum.  Passed to vgg19_features / closure_eval they replace this evaluation's own decisions, so that two fp32
+    evaluations whose pre-activations differ in the last bits are compared under EQUAL decisions: a pre-activation
+    within rounding of 0 otherwise lands on different sides and changes the gradient over that unit's whole receptive
+    field.  (The tests also check that the two evaluations' own decisions differ only at such near-ties.)"""
+
+    def __init__(self, activations: Sequence[torch.Tensor]):
+        assert len(activations) == len(VGG19_CONVS)
+        self.relu = [a > 0 for a in activations]
+        self.pool = {}
+        for (name, _, _), a in zip(VGG19_CONVS, activations):
+            if name in POOL_AFTER:
+                self.pool[name] = F.max_pool2d(a, kernel_size=2, stride=2, return_indices=True)[1]
+
+
+def vgg19_features(x: torch.Tensor, weights: Sequence[Tuple[torch.Tensor, torch.Tensor]],
+                   decisions: Optional[Decisions] = None, record: Optional[list] = None):
+    """Returns the 6 maps (relu1_1, relu2_1, relu3_1, relu4_1, ReLU(conv4_2), relu5_1).  `decisions`: see Decisions
+    (None = this evaluation's own: the reference's forward).  `record` (a list) receives the 13 pre-activations."""
     outs = []
-    for (name, _, _), (w, b) in zip(VGG19_CONVS, weights):
-        x = F.relu(F.conv2d(x, w, b, stride=1, padding=1))
+    for li, ((name, _, _), (w, b)) in enumerate(zip(VGG19_CONVS, weights)):
+        pre = F.conv2d(x, w, b, stride=1, padding=1)
+        if record is not None:
+            record.append(pre.detach())
+        x = F.relu(pre) if decisions is None else pre * decisions.relu[li].to(pre.dtype)
         if name in TAPS:
             outs.append(x)
         if name in POOL_AFTER:
-            x = F.max_pool2d(x, kernel_size=2, stride=2)
+            if decisions is None:
+                x = F.max_pool2d(x, kernel_size=2, stride=2)
+            else:
+                idx = decisions.pool[name]
+                x = x.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
     return outs
 
 
@@ -151,10 +187,11 @@ class LevelTargets:
             self.grams = [gram_matrix(sf[i]) for i in STYLE_INDICES]
 
 
-def level_loss(x: torch.Tensor, tg: LevelTargets, weights, cw: float, sw: float, tvw: float):
+def level_loss(x: torch.Tensor, tg: LevelTargets, weights, cw: float, sw: float, tvw: float,
+               decisions: Optional[Decisions] = None, record: Optional[list] = None):
     """(total, content, style, tv) of one level (neural_style_transfer.py:84-112).
     The reference's per-closure ``0 * randn`` noise term (:91-93) contributes exactly 0."""
-    feats = vgg19_features(x, weights)
+    feats = vgg19_features(x, weights, decisions, record)
     content = F.mse_loss(tg.content, feats[CONTENT_INDEX].squeeze(0), reduction="mean")
     style = 0.0
     for g_gt, i in zip(tg.grams, STYLE_INDICES):
@@ -166,16 +203,22 @@ def level_loss(x: torch.Tensor, tg: LevelTargets, weights, cw: float, sw: float,
 
 
 def closure_eval(x: torch.Tensor, targets: Sequence[LevelTargets], weights,
-                 cw: float, sw: float, tvw: float):
+                 cw: float, sw: float, tvw: float, decisions: Optional[Sequence[Decisions]] = None,
+                 record: Optional[list] = None):
     """One closure evaluation (neural_style_transfer.py:152-199, without the LR decay and
     prints): returns (total_loss float32 tensor, grad (1,3,H,W), per-level rows
-    [(total, content, style, tv), ...])."""
+    [(total, content, style, tv), ...]).  `decisions` (one Decisions per level): evaluate under another pass's
+    ReLU / pooling decisions; `record` receives one list of 13 pre-activations per level."""
     x = x.detach().clone().requires_grad_(True)
     levels, total, rows = [x], None, []
     for i, tg in enumerate(targets):
         if i > 0:      # same op order as the reference: autograd's accumulation order follows it
             levels.append(bicubic_half(levels[i - 1]))
-        t, c, s, tv = level_loss(levels[i], tg, weights, cw, sw, tvw)
+        rec = None
+        if record is not None:
+            rec = []
+            record.append(rec)
+        t, c, s, tv = level_loss(levels[i], tg, weights, cw, sw, tvw, decisions[i] if decisions is not None else None, rec)
         total = t if total is None else 1.0 * total + t
         rows.append((float(t.detach()), float(c.detach()), float(s.detach()), float(tv.detach())))
     total.backward()

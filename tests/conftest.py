@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# no pretrained VGG19 file exists offline: the tests opt into the seeded synthetic weights explicitly (the product
+# raises without a checkpoint; tests/test_host_api.py checks that)
+os.environ.setdefault("NST_SYNTHETIC_WEIGHTS", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
@@ -29,4 +33,4 @@ def golden():
 @pytest.fixture(scope="session")
 def vgg_weights():
     from oracle import cpu_ref
-    return cpu_ref.synthetic_vgg19_weights()
+    return cpu_ref.synthetic_vgg19_weights(bias_std=cpu_ref.TEST_BIAS_STD)

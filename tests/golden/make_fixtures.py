@@ -253,6 +253,18 @@ def _ref_closure(ref_mu, ref_nst, content_levels, style_levels, x_img, cw, sw, t
     return float(total), np.array(rows, dtype=np.float64), x.grad.detach()
 
 
+def _ref_term_grads(ref_mu, ref_nst, content_levels, style_levels, x_img):
+    """The pixel gradient of each loss term alone - (cw,0,0), (0,sw,0), (0,0,tvw) through the same LossBuilder -
+    so that a parity test can hold every term separately (a term that is < 3e-3 of the summed gradient's norm could
+    otherwise be wrong or absent unnoticed)."""
+    out = {}
+    for tag, wts in (("c", (1e3, 0.0, 0.0)), ("s", (0.0, 4e5, 0.0)), ("tv", (0.0, 0.0, 1e2))):
+        total, _, grad = _ref_closure(ref_mu, ref_nst, content_levels, style_levels, x_img, *wts)
+        out[f"grad_{tag}"] = grad.numpy()
+        out[f"total_{tag}"] = np.float64(total)
+    return out
+
+
 def fx_closure_small(ref_mu, ref_nn, ref_nst, weights):
     """2 levels, 64x96 + 32x48: inputs, losses and the whole gradient."""
     cl = _levels(64, 96, 2, seed=1)
@@ -260,7 +272,8 @@ def fx_closure_small(ref_mu, ref_nn, ref_nst, weights):
     x_img = (0.6 * cl[0] + 0.4 * cpu_ref.synthetic_image(64, 96, seed=9)).astype(np.float32)
     total, rows, grad = _ref_closure(ref_mu, ref_nst, cl, sl, x_img, 1e3, 4e5, 1e2)
     save("closure_64x96_L1", content0=cl[0], content1=cl[1], style0=sl[0], style1=sl[1], x_img=x_img,
-         total=np.float64(total), rows=rows, grad=grad.numpy())
+         total=np.float64(total), rows=rows, grad=grad.numpy(),
+         **_ref_term_grads(ref_mu, ref_nst, cl, sl, x_img))
 
 
 def fx_closure_odd(ref_mu, ref_nn, ref_nst, weights):
@@ -270,7 +283,7 @@ def fx_closure_odd(ref_mu, ref_nn, ref_nst, weights):
     x_img = (0.5 * c[0] + 0.5 * cpu_ref.synthetic_image(50, 76, seed=9)).astype(np.float32)
     total, rows, grad = _ref_closure(ref_mu, ref_nst, c, s, x_img, 1e3, 4e5, 1e2)
     save("closure_50x76_L0", content0=c[0], style0=s[0], x_img=x_img,
-         total=np.float64(total), rows=rows, grad=grad.numpy())
+         total=np.float64(total), rows=rows, grad=grad.numpy(), **_ref_term_grads(ref_mu, ref_nst, c, s, x_img))
 
 
 def fx_closure_L0(ref_mu, ref_nn, ref_nst, weights):
@@ -355,8 +368,49 @@ def fx_lbfgs_small(ref_mu, ref_nn, ref_nst, weights):
              final=summarize(torch.from_numpy(imgs[-1][0]), k=256, seed=51))
 
 
+def _moved(imgs, init):
+    out, prev = [], init
+    for img, _ in imgs:
+        out.append(bool(np.any(img != prev)))
+        prev = img
+    return np.array(out, dtype=np.bool_)
+
+
+def fx_lbfgs_config2(ref_mu, ref_nn, ref_nst, weights):
+    """BASELINE config 2 at its full iteration count: L=1 (768x512 + 384x256), L-BFGS exactly as the reference
+    constructs it, 500 closures, content top level as the initial image.  ~25 min of CPU."""
+    cl = _levels(512, 768, 2, seed=1)
+    sl = _levels(512, 768, 2, seed=2)
+    rows, imgs = _run_reference_process(ref_mu, ref_nst, cl, sl, cl[0], "lbfgs", 500)
+    save("traj_lbfgs_512x768_L1_500", rows=rows, steps=np.array([s for _, s in imgs], dtype=np.int64),
+         moved=_moved(imgs, cl[0]), final=summarize(torch.from_numpy(imgs[-1][0]), k=1024, seed=61),
+         after_1=summarize(torch.from_numpy(imgs[0][0]), k=1024, seed=62))
+
+
+def fx_adam_config2geo(ref_mu, ref_nn, ref_nst, weights):
+    """The config-2 geometry under Adam (a job whose image moves at every step), 100 iterations."""
+    cl = _levels(512, 768, 2, seed=1)
+    sl = _levels(512, 768, 2, seed=2)
+    rows, imgs = _run_reference_process(ref_mu, ref_nst, cl, sl, cl[0], "adam", 100)
+    save("traj_adam_512x768_L1_100", rows=rows, steps=np.array([s for _, s in imgs], dtype=np.int64),
+         final=summarize(torch.from_numpy(imgs[-1][0]), k=1024, seed=63),
+         after_1=summarize(torch.from_numpy(imgs[0][0]), k=1024, seed=64),
+         after_10=summarize(torch.from_numpy(imgs[9][0]), k=1024, seed=65))
+
+
+def fx_lbfgs_config2geo_legacy(ref_mu, ref_nn, ref_nst, weights):
+    """The config-2 geometry under L-BFGS with the legacy 25-evaluation line search (max_eval=26 through the
+    constructor argument only): steps are accepted and the curvature history grows; 100 closures."""
+    cl = _levels(512, 768, 2, seed=1)
+    sl = _levels(512, 768, 2, seed=2)
+    rows, imgs = _run_reference_process(ref_mu, ref_nst, cl, sl, cl[0], "lbfgs", 100, lbfgs_max_eval=26)
+    save("traj_lbfgs_512x768_L1_legacy_100", rows=rows, steps=np.array([s for _, s in imgs], dtype=np.int64),
+         moved=_moved(imgs, cl[0]), final=summarize(torch.from_numpy(imgs[-1][0]), k=1024, seed=66))
+
+
 ALL = {f.__name__[3:]: f for f in (fx_kat, fx_bicubic, fx_vgg, fx_closure_small, fx_closure_odd, fx_closure_L0,
-                                   fx_adam_small, fx_lbfgs_small, fx_adam_L0)}
+                                   fx_adam_small, fx_lbfgs_small, fx_adam_L0, fx_adam_config2geo,
+                                   fx_lbfgs_config2geo_legacy, fx_lbfgs_config2)}
 
 
 def main():
@@ -364,7 +418,7 @@ def main():
     ap.add_argument("--only", nargs="*", default=None)
     args = ap.parse_args()
     torch.manual_seed(0)
-    weights = cpu_ref.synthetic_vgg19_weights()
+    weights = cpu_ref.synthetic_vgg19_weights(bias_std=cpu_ref.TEST_BIAS_STD)     # non-zero biases
     install_standins(weights)
     ref_mu, ref_nn, ref_nst = import_reference()
     for name, fn in ALL.items():

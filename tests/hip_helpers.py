@@ -1,0 +1,206 @@
+"""Shared helpers of the GPU parity tests (tests/test_hip_*.py)."""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import cpu_ref
+
+# Whole-gradient cap of a teacher-forced closure.  Arithmetic agrees to ~1e-6; what sets this bound are ReLU /
+# max-pool DECISIONS: a pre-activation within one ulp of 0 lands on different sides in two fp32 evaluations that sum in
+# different orders, and one flipped unit at conv4/conv5 depth moves the pixel gradient over its whole receptive field
+# (measured: one flipped unit of 49152 at ReLU(conv4_2) = 2e-3 of the content gradient at 64x96; the torch-fp32 oracle
+# itself sits 2e-4 ... 2.4e-3 from an fp64 evaluation of the same closure).  The cap alone would also pass a wrong or
+# missing small loss term, so every closure test goes through assert_grad_close below, per loss term.
+GRAD_RTOL = 3e-3
+# outside the receptive fields of flipped units the gradient must agree like any other fp32 quantity
+BULK_RTOL = 2e-5
+
+CW, SW, TVW = 1e3, 4e5, 1e2
+TERMS = (("all", (CW, SW, TVW)), ("content", (CW, 0.0, 0.0)), ("style", (0.0, SW, 0.0)), ("tv", (0.0, 0.0, TVW)))
+
+_REPORT = os.environ.get("NST_TEST_REPORT")
+
+
+def report(line: str) -> None:
+    """Measurements the tolerances were chosen from: appended to $NST_TEST_REPORT when set (gpurun_out/...)."""
+    print(line)
+    if _REPORT:
+        with open(_REPORT, "a") as f:
+            f.write(line + "\n")
+
+
+def dev(t):
+    return t.contiguous().to("cuda:0")
+
+
+def rel_l2(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def check_rows(rows, ref_rows, rtol, cw=CW, sw=SW, tvw=TVW):
+    """Loss rows (total, content, style, tv): totals relatively; each component by its weighted
+    contribution to the level total (a content loss of 1e-10 is rounding noise, not a quantity)."""
+    rows = np.asarray(rows, dtype=np.float64)
+    ref = np.asarray(ref_rows, dtype=np.float64)
+    assert rows.shape == ref.shape
+    np.testing.assert_allclose(rows[..., 0], ref[..., 0], rtol=rtol)
+    for j, wgt in ((1, cw), (2, sw), (3, tvw)):
+        err = np.abs(rows[..., j] - ref[..., j]) * wgt
+        assert np.all(err <= rtol * np.abs(ref[..., 0])), (j, float(err.max()))
+
+
+def rows_rel_err(rows, ref_rows):
+    """Largest relative error of the level totals (what check_rows' rtol is compared with)."""
+    rows = np.asarray(rows, dtype=np.float64)
+    ref = np.asarray(ref_rows, dtype=np.float64)
+    return float(np.max(np.abs(rows[..., 0] - ref[..., 0]) / np.abs(ref[..., 0])))
+
+
+def levels(h, w, nlev, seed):
+    """Pyramid of synthetic images, highest-res first (same construction as tests/golden/make_fixtures.py)."""
+    top = cpu_ref.synthetic_image(h, w, seed)
+    out = [top]
+    t = torch.from_numpy(top).permute(2, 0, 1).unsqueeze(0)
+    for l in range(1, nlev):
+        d = F.interpolate(t, size=(h >> l, w >> l), mode="bicubic", align_corners=False)
+        out.append(d.squeeze(0).permute(1, 2, 0).contiguous().numpy())
+    return out
+
+
+def setup(eng, contents, styles):
+    nlev = len(contents)
+    h, w = contents[0].shape[:2]
+    eng.configure(nlev, h, w)
+    for i in range(nlev):
+        eng.set_targets(i, dev(cpu_ref.prepare_img(contents[i])), dev(cpu_ref.prepare_img(styles[i])))
+
+
+def oracle_targets(contents, styles, weights):
+    return [cpu_ref.LevelTargets(cpu_ref.prepare_img(c), cpu_ref.prepare_img(s), weights) for c, s in zip(contents, styles)]
+
+
+def grad_stats(got, ref):
+    """(rel-L2 of the whole, share of entries inside flipped receptive fields, rel-L2 of the rest)."""
+    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
+    full = rel_l2(got, ref)
+    err = np.abs(got - ref)
+    bad = err > 1e-4 * np.abs(ref).max()
+    bulk = float(np.linalg.norm((got - ref)[~bad]) / max(np.linalg.norm(ref[~bad]), 1e-30))
+    return full, float(bad.mean()), bulk
+
+
+def assert_grad_close(got, ref, what="", cap=GRAD_RTOL, max_flipped=0.02, bulk=BULK_RTOL):
+    """Flip-aware gradient comparison.  Either the whole gradient agrees to `bulk` (2e-5 rel-L2), or: the entries
+    that differ by more than 1e-4 of the largest gradient - the receptive fields of ReLU / pooling decisions that fell
+    on the other side - are few (`max_flipped` of the pixels), everything outside them agrees to `bulk`, and the whole
+    stays under `cap`."""
+    full, flipped, rest = grad_stats(got, ref)
+    report(f"grad {what}: rel-L2 {full:.2e}, flipped-field entries {flipped:.3%}, rest rel-L2 {rest:.2e}")
+    if full < bulk:
+        return
+    assert flipped < max_flipped and rest < bulk and full < cap, (what, full, flipped, rest)
+
+
+def check_summary(t, fx, key, atol, rtol=0.0):
+    """A tensor against a fixture summary written by make_fixtures.summarize (sampled values + moments)."""
+    flat = torch.as_tensor(t).detach().reshape(-1).cpu()
+    assert list(torch.as_tensor(t).shape) == list(fx[f"{key}.shape"])
+    idx = torch.from_numpy(fx[f"{key}.idx"])
+    np.testing.assert_allclose(flat[idx].numpy(), fx[f"{key}.val"], rtol=rtol, atol=atol)
+    return float(np.max(np.abs(flat[idx].numpy() - fx[f"{key}.val"])))
+
+
+# ---- comparison under equal ReLU / pooling decisions -------------------------------------------------------------
+def device_decisions(eng):
+    """cpu_ref.Decisions of the closure the engine evaluated last, one per pyramid level."""
+    return [cpu_ref.Decisions([a.cpu() for a in eng.level_activations(l)]) for l in range(eng.levels)]
+
+
+def decision_disagreements(pre, dec):
+    """Where this (oracle) evaluation's own decisions differ from `dec` (the device pass's): (share of ReLU units,
+    largest |pre-activation| at such a unit relative to the layer's rms, share of pooling windows with a positive
+    maximum that chose another position, largest gap between the two candidates relative to the layer's rms)."""
+    units = flips = 0
+    worst = 0.0
+    windows = moved = 0
+    worst_gap = 0.0
+    for li, ((name, _, _), p) in enumerate(zip(cpu_ref.VGG19_CONVS, pre)):
+        rms = float(p.double().pow(2).mean().sqrt())
+        diff = (p > 0) != dec.relu[li]
+        units += diff.numel()
+        n = int(diff.sum())
+        flips += n
+        if n:
+            worst = max(worst, float(p[diff].abs().max()) / rms)
+        if name in cpu_ref.POOL_AFTER:
+            a = torch.relu(p)
+            own_val, own_idx = torch.nn.functional.max_pool2d(a, 2, 2, return_indices=True)
+            idx = dec.pool[name]
+            other_val = a.flatten(2).gather(2, idx.flatten(2)).view(idx.shape)
+            d = (own_idx != idx) & (own_val > 0)
+            windows += d.numel()
+            m = int(d.sum())
+            moved += m
+            if m:
+                worst_gap = max(worst_gap, float((own_val - other_val)[d].max()) / rms)
+    return flips / max(units, 1), worst, moved / max(windows, 1), worst_gap
+
+
+# a decision may differ between two fp32 evaluations only where the quantity it tests is within accumulated rounding of
+# the decision point: |pre-activation| (or the gap between two pooling candidates) below this share of the layer's rms
+NEAR_TIE = 1e-4
+
+
+def closure_vs_oracle_under_equal_decisions(eng, xt, tg, weights, what, terms=TERMS, grad_tol=BULK_RTOL, loss_tol=1e-5,
+                                            cap=GRAD_RTOL):
+    """The strict form of the closure parity test.  For the weighted sum and for every loss term alone:
+    (1) losses against the oracle's own evaluation (rel <= 1e-5);
+    (2) the device pass's ReLU / pooling decisions differ from the oracle's own only at near-ties (NEAR_TIE), in a
+        small share of the units;
+    (3) under the DEVICE's decisions (cpu_ref.Decisions) the oracle's gradient must be the device's: rel-L2 <=
+        2e-5 over the WHOLE gradient, no entry excluded (measured 3e-7 ... 3e-6);
+    (4) against the oracle's own decisions the whole stays under `cap` = GRAD_RTOL (what the flipped near-ties cost);
+    (5) on the device the terms add up: g(all) = g(content) + g(style) + g(tv) to fp32 summation error - every term
+        is in the sum with its weight (the decisions of the four device passes are the same: one forward)."""
+    nlev = eng.levels
+    xd = dev(xt)
+    parts = {}
+    for name, (cw, sw, tvw) in terms:
+        grad, losses = eng.closure(xd, cw, sw, tvw)
+        dec = device_decisions(eng)
+        losses = losses.cpu().numpy()
+        g = grad.cpu().numpy()
+        parts[name] = g.astype(np.float64)
+        rec = []
+        loss, grad_own, rows = cpu_ref.closure_eval(xt, tg, weights, cw, sw, tvw, record=rec)
+        assert float(losses[-1]) == pytest_approx(float(loss), loss_tol), (what, name, float(losses[-1]), float(loss))
+        check_rows(losses[:-1].reshape(nlev, 4), np.array(rows), 2 * loss_tol, cw, sw, tvw)
+        if name == "tv":
+            assert rel_l2(g, grad_own.numpy()) < 5e-6, name                 # no network, no decisions
+            continue
+        stats = [decision_disagreements(rec[l], dec[l]) for l in range(nlev)]
+        share = max(s[0] for s in stats); tie = max(s[1] for s in stats)
+        pshare = max(s[2] for s in stats); ptie = max(s[3] for s in stats)
+        loss_f, grad_forced, _ = cpu_ref.closure_eval(xt, tg, weights, cw, sw, tvw, decisions=dec)
+        e_forced, e_own = rel_l2(g, grad_forced.numpy()), rel_l2(g, grad_own.numpy())
+        report(f"closure {what} [{name}]: gradient rel-L2 under equal decisions {e_forced:.2e}, under the oracle's own {e_own:.2e}; "
+               f"decisions differ at {share:.2e} of the ReLU units (largest |pre|/rms there {tie:.1e}) and {pshare:.2e} of the "
+               f"pooling windows (gap/rms {ptie:.1e})")
+        assert share < 1e-3 and tie < NEAR_TIE and pshare < 1e-3 and ptie < NEAR_TIE, (what, name, stats)
+        assert abs(float(loss_f) - float(loss)) <= 1e-5 * abs(float(loss))   # forcing near-ties does not move the loss
+        assert e_forced < grad_tol, (what, name, e_forced)
+        assert e_own < cap, (what, name, e_own)
+    if all(k in parts for k in ("all", "content", "style", "tv")):
+        s = parts["content"] + parts["style"] + parts["tv"]
+        add = float(np.linalg.norm(parts["all"] - s) / np.linalg.norm(s))
+        report(f"closure {what}: |g(all) - sum of the terms| / |.| = {add:.1e}")
+        assert add < 2e-6, (what, add)
+
+
+def pytest_approx(value, rel):
+    import pytest
+    return pytest.approx(value, rel=rel)

@@ -1,11 +1,22 @@
-"""GPU: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs and
-against the fixtures produced by the reference.  Tolerances are stated per test; all arithmetic
-is fp32 on both sides (exact-f32 MFMA on the device), so differences are summation order only."""
+"""GPU: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs and against the fixtures
+produced by the reference itself.  Kernels, network, closure.  (Optimisers and full-length trajectories:
+tests/test_hip_optim.py; serving behaviour and the communicator: tests/test_hip_serving.py.)
+
+Values are fp32 on both sides.  On the device the 3x3 convolutions and the Gram products default to the f16x2
+arithmetic - every fp32 operand cut into two scaled fp16 pieces, 3 fp16 MFMAs per product block, fp32 accumulation -
+whose error against an fp64 evaluation is that of an fp32 MFMA (test_closure_accuracy_vs_fp64_truth holds it to 3x
+torch-fp32's own error); the exact-f32-MFMA and bf16x3 modes are held against it in every run.  The weight set of
+every parity test carries seeded NON-ZERO biases (cpu_ref.TEST_BIAS_STD).  Tolerances are stated per test."""
+import functools
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import cpu_ref
+from hip_helpers import (BULK_RTOL, CW, GRAD_RTOL, SW, TERMS, TVW, assert_grad_close, check_rows,
+                         closure_vs_oracle_under_equal_decisions, dev, rel_l2, report, levels as _levels, setup as _setup,
+                         oracle_targets)
 
 pytestmark = pytest.mark.gpu
 
@@ -16,28 +27,6 @@ def eng(vgg_weights):
     e = StyleEngine(vgg_weights, 0)
     yield e
     e.close()
-
-
-def dev(t):
-    return t.contiguous().to("cuda:0")
-
-
-def rel_l2(a, b):
-    a = np.asarray(a, dtype=np.float64)
-    b = np.asarray(b, dtype=np.float64)
-    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
-
-
-def check_rows(rows, ref_rows, rtol, cw=1e3, sw=4e5, tvw=1e2):
-    """Loss rows (total, content, style, tv): totals relatively; each component by its weighted
-    contribution to the level total (a content loss of 1e-10 is rounding noise, not a quantity)."""
-    rows = np.asarray(rows, dtype=np.float64)
-    ref = np.asarray(ref_rows, dtype=np.float64)
-    assert rows.shape == ref.shape
-    np.testing.assert_allclose(rows[..., 0], ref[..., 0], rtol=rtol)
-    for j, wgt in ((1, cw), (2, sw), (3, tvw)):
-        err = np.abs(rows[..., j] - ref[..., j]) * wgt
-        assert np.all(err <= rtol * np.abs(ref[..., 0])), (j, float(err.max()))
 
 
 # ---------------------------------------------------------------- small kernels
@@ -148,20 +137,9 @@ def test_vgg_features_vs_reference_fixture(eng, golden):
     np.testing.assert_allclose(outs[4].cpu().numpy(), fx["out4_full"], rtol=1e-4, atol=1e-4)
 
 
-def assert_backward_close(got, ref, what=""):
-    """Backward of the frozen network for given output gradients.  Arithmetic agreement is 2e-5 (rel-L2); a ReLU
-    pre-activation or a pooling tie within rounding of the decision point can fall on the other side in two fp32
-    evaluations, which changes the gradient inside that unit's receptive field only: such entries are allowed if
-    they are few (< 2 % of the pixels differ by more than 1e-4 of the largest gradient) and small overall."""
-    got, ref = np.asarray(got, np.float64), np.asarray(ref, np.float64)
-    full = rel_l2(got, ref)
-    if full < 2e-5:
-        return
-    err = np.abs(got - ref)
-    bad = err > 1e-4 * np.abs(ref).max()
-    bulk = np.linalg.norm((got - ref)[~bad]) / max(np.linalg.norm(ref[~bad]), 1e-30)
-    print(f"backward {what}: rel-L2 {full:.2e}, {bad.mean():.2%} entries in flipped receptive fields, bulk rel-L2 {bulk:.2e}")
-    assert bad.mean() < 0.02 and bulk < 2e-5 and full < 3e-2, (what, full, float(bad.mean()), bulk)
+# Backward of the frozen network for injected output gradients: the flip-aware comparison of hip_helpers with a loose cap
+# on the whole (random injected gradients weight every unit alike, so one flipped deep unit weighs more than in a loss)
+assert_backward_close = functools.partial(assert_grad_close, cap=3e-2)
 
 
 @pytest.mark.parametrize("h,w", [(48, 80), (35, 51)])
@@ -191,64 +169,58 @@ def test_vgg_backward_vs_autograd(eng, vgg_weights, golden, h, w):
 
 
 # ---------------------------------------------------------------- closure
-def _setup(eng, contents, styles):
-    nlev = len(contents)
-    h, w = contents[0].shape[:2]
-    eng.configure(nlev, h, w)
-    for i in range(nlev):
-        eng.set_targets(i, dev(cpu_ref.prepare_img(contents[i])), dev(cpu_ref.prepare_img(styles[i])))
-
-
-# Teacher-forced closure tolerances.  Loss: rel <= 1e-5 (measured <= 3e-7).  Gradient: rel-L2 <= GRAD_RTOL.
-# The gradient bound is set by ReLU / max-pool decisions, not by arithmetic: a pre-activation within one
-# ulp of 0 lands on different sides in two fp32 evaluations with different summation orders, and one
-# flipped unit at conv4/conv5 depth moves the pixel gradient over its whole receptive field (measured:
-# a single flipped unit of 49152 at ReLU(conv4_2) = 2e-3 of the content gradient at 64x96).  The
-# torch-fp32 oracle itself sits 3e-4 from an fp64 evaluation of the same closure at 128x192 and 256x384.
-GRAD_RTOL = 3e-3
+def closure_terms_vs(eng, x, ref_of_term, nlev, what):
+    """The closure with all three loss terms and with each term alone - (cw,0,0), (0,sw,0), (0,0,tvw) - against
+    ref_of_term(name, weights) -> (total, grad, rows or None).  Loss: rel <= 1e-5 (measured <= 3e-7).  Gradient: the
+    flip-aware comparison per term (hip_helpers.assert_grad_close): outside the receptive fields of flipped ReLU / pool
+    decisions rel-L2 <= 2e-5, the whole under GRAD_RTOL; the TV term passes no network, so it must agree outright."""
+    for name, (cw, sw, tvw) in TERMS:
+        total, grad_ref, rows = ref_of_term(name, (cw, sw, tvw))
+        grad, losses = eng.closure(x, cw, sw, tvw)
+        losses = losses.cpu().numpy()
+        assert float(losses[-1]) == pytest.approx(float(total), rel=1e-5), name
+        if rows is not None:
+            check_rows(losses[:-1].reshape(nlev, 4), np.array(rows), 2e-5, cw, sw, tvw)
+        g = grad.cpu().numpy()
+        if name == "tv":
+            assert rel_l2(g, grad_ref) < 5e-6, name
+        else:
+            assert_grad_close(g, grad_ref, f"{what} [{name}]")
 
 
 @pytest.mark.parametrize("name,nlev", [("closure_64x96_L1", 2), ("closure_50x76_L0", 1)])
 def test_closure_vs_reference_fixture(eng, vgg_weights, golden, name, nlev):
+    """Teacher-forced closure against what the reference's own LossBuilder + autograd produced (fixtures hold the whole
+    gradient of the weighted sum and of every term alone)."""
     fx = golden(name)
     _setup(eng, [fx[f"content{i}"] for i in range(nlev)], [fx[f"style{i}"] for i in range(nlev)])
     x = dev(cpu_ref.prepare_img(fx["x_img"]))
-    grad, losses = eng.closure(x, 1e3, 4e5, 1e2)
-    losses = losses.cpu().numpy()
-    assert float(losses[-1]) == pytest.approx(float(fx["total"]), rel=1e-5)
-    check_rows(losses[:-1].reshape(nlev, 4), fx["rows"], 2e-5)
-    assert rel_l2(grad.cpu().numpy(), fx["grad"]) < GRAD_RTOL
+
+    def ref(term, weights):
+        if term == "all":
+            return fx["total"], fx["grad"], fx["rows"]
+        tag = {"content": "c", "style": "s", "tv": "tv"}[term]
+        return fx[f"total_{tag}"], fx[f"grad_{tag}"], None
+
+    closure_terms_vs(eng, x, ref, nlev, name)
     # run-to-run bitwise reproducibility (ordered reductions, no float atomics)
-    grad2, losses2 = eng.closure(x, 1e3, 4e5, 1e2)
-    assert torch.equal(grad, grad2) and np.array_equal(losses, losses2.cpu().numpy())
-
-
-def _levels(h, w, nlev, seed):
-    import torch.nn.functional as F
-    top = cpu_ref.synthetic_image(h, w, seed)
-    out = [top]
-    t = torch.from_numpy(top).permute(2, 0, 1).unsqueeze(0)
-    for l in range(1, nlev):
-        d = F.interpolate(t, size=(h >> l, w >> l), mode="bicubic", align_corners=False)
-        out.append(d.squeeze(0).permute(1, 2, 0).contiguous().numpy())
-    return out
+    grad, losses = eng.closure(x, CW, SW, TVW)
+    grad2, losses2 = eng.closure(x, CW, SW, TVW)
+    assert torch.equal(grad, grad2) and torch.equal(losses, losses2)
 
 
 @pytest.mark.parametrize("h,w,nlev,hs,ws", [(128, 192, 3, 128, 192), (96, 80, 2, 70, 110), (256, 384, 1, 256, 384),
                                             (128, 190, 2, 100, 150),      # real-photo geometry: 383x256-like odd level
                                             (288, 300, 3, 288, 300)])
 def test_closure_vs_oracle(eng, vgg_weights, golden, h, w, nlev, hs, ws):
+    """Teacher-forced closure against the oracle, all terms and each alone, gradients under equal ReLU / pooling
+    decisions: hip_helpers.closure_vs_oracle_under_equal_decisions states the five checks."""
     c, s = _levels(h, w, nlev, 1), _levels(hs, ws, nlev, 2)
     _setup(eng, c, s)
-    tg = [cpu_ref.LevelTargets(cpu_ref.prepare_img(ci), cpu_ref.prepare_img(si), vgg_weights) for ci, si in zip(c, s)]
+    tg = oracle_targets(c, s, vgg_weights)
     x_img = (0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(h, w, seed=9)).astype(np.float32)
     xt = cpu_ref.prepare_img(x_img)
-    loss, grad_ref, rows = cpu_ref.closure_eval(xt, tg, vgg_weights, 1e3, 4e5, 1e2)
-    grad, losses = eng.closure(dev(xt), 1e3, 4e5, 1e2)
-    losses = losses.cpu().numpy()
-    assert float(losses[-1]) == pytest.approx(float(loss), rel=1e-5)
-    check_rows(losses[:-1].reshape(nlev, 4), np.array(rows), 2e-5)
-    assert rel_l2(grad.cpu().numpy(), grad_ref.numpy()) < GRAD_RTOL
+    closure_vs_oracle_under_equal_decisions(eng, xt, tg, vgg_weights, f"{h}x{w}x{nlev}")
     if (h, w, nlev) == (256, 384, 1):
         fx = golden("closure_256x384_L0")
         x0 = cpu_ref.prepare_img(c[0])
@@ -291,34 +263,54 @@ def test_closure_accuracy_vs_fp64_truth(eng, vgg_weights, h, w, nlev):
         assert e_hip < max(3.0 * e_t32, 5e-7), (i, e_hip, e_t32)
 
 
-@pytest.mark.parametrize("env", [{"NST_CONV": "bf16x3"}, {"NST_CONV": "f32"}, {"NST_BATCH": "0"}, {"NST_BATCH": "0", "NST_SINGLE_STREAM": "1"},
-                                 {"NST_CONV": "f32", "NST_BATCH": "0"}, {"NST_BATCH": "0", "NST_H2_BAND_ROWS": "16"},
-                                 {"NST_BATCH": "0", "NST_SINGLE_STREAM": "1", "NST_H2_BAND_ROWS": "32"}])
-def test_closure_execution_modes_agree(eng, vgg_weights, monkeypatch, env):
-    """The alternative schedules / arithmetic (fp32-MFMA convs; one launch per level on per-level streams or on one
-    stream; the row-band launches that tensors beyond 4 GiB take, forced onto these small images) must give the
-    default path's closure (f16x2 convs, one launch per layer over all levels)."""
+@pytest.mark.parametrize("opts", [dict(conv_mode="bf16x3"), dict(conv_mode="f32"), dict(batched=False),
+                                  dict(batched=False, single_stream=True), dict(conv_mode="f32", batched=False),
+                                  dict(batched=False, h2_band_rows=16),
+                                  dict(batched=False, single_stream=True, h2_band_rows=32), dict(use_graph=True)])
+def test_closure_execution_modes_agree(eng, vgg_weights, opts):
+    """The alternative schedules / arithmetic (nst_options: fp32-MFMA and bf16x3 convs; one launch per level on
+    per-level streams or on one stream; the row-band launches that tensors beyond 4 GiB take, forced onto these small
+    images; hipGraph replay): each against the ORACLE under its own decisions (gradient 2e-5 on the whole, per term),
+    and against the default path's losses (f16x2 convs, one launch per layer over all levels) to 1e-5."""
     from artstyletransfer_amd.engine import StyleEngine
     c, s = _levels(128, 192, 3, 1), _levels(96, 160, 3, 2)
-    x = dev(cpu_ref.prepare_img((0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(128, 192, seed=9)).astype(np.float32)))
+    xt = cpu_ref.prepare_img((0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(128, 192, seed=9)).astype(np.float32))
+    x = dev(xt)
     _setup(eng, c, s)
-    g0, l0 = eng.closure(x, 1e3, 4e5, 1e2)
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
-    other = StyleEngine(vgg_weights, 0)
+    tg = oracle_targets(c, s, vgg_weights)
+    other = StyleEngine(vgg_weights, 0, **opts)
     try:
-        assert other.conv_mode() == env.get("NST_CONV", "f16x2")
+        assert other.conv_mode() == opts.get("conv_mode", "f16x2")
         _setup(other, c, s)
-        g1, l1 = other.closure(x, 1e3, 4e5, 1e2)
+        closure_vs_oracle_under_equal_decisions(other, xt, tg, vgg_weights, f"mode {opts}")
+        g0, l0 = eng.closure(x, CW, SW, TVW)
+        g1 = l1 = None
+        for _ in range(3 if opts.get("use_graph") else 1):     # same buffers again: captured on the 2nd call, replayed on the 3rd
+            g1, l1 = other.closure(x, CW, SW, TVW, g1, l1)
         np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=1e-5, atol=1e-7)
-        assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < GRAD_RTOL
+        if "conv_mode" not in opts:                              # same arithmetic, another schedule: same decisions
+            assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-5
     finally:
         other.close()
 
 
+def test_options_default_to_the_environment(vgg_weights, monkeypatch):
+    """nst_options fields left at -1 take the environment, read once at context creation; an explicit option wins."""
+    from artstyletransfer_amd.engine import StyleEngine
+    monkeypatch.setenv("NST_CONV", "bf16x3")
+    a = StyleEngine(vgg_weights, 0)
+    b = StyleEngine(vgg_weights, 0, conv_mode="f32")
+    monkeypatch.setenv("NST_CONV", "f16x2")            # changing it afterwards does not reach a living context
+    try:
+        assert a.conv_mode() == "bf16x3" and b.conv_mode() == "f32"
+    finally:
+        a.close()
+        b.close()
+
+
 @pytest.mark.parametrize("geo", [(63, 133, 1, 227, 293), (356, 151, 3, 356, 151), (103, 151, 3, 136, 329),
                                  (89, 320, 2, 89, 320), (290, 32, 2, 290, 32), (336, 77, 3, 104, 271)])
-def test_f16x2_vs_exact_f32_mfma_random_geometries(vgg_weights, monkeypatch, geo):
+def test_f16x2_vs_exact_f32_mfma_random_geometries(vgg_weights, geo):
     """Odd sizes, foreign-size styles, 1-3 levels (geometries drawn by tools/fuzz_modes.py, which ran 40 of them):
     the default closure (fp16-piece convolutions, batched levels, fused un-pooling, buffer-addressed epilogues on
     interior tiles and the general form on edge tiles) against the same library's exact-f32-MFMA closure on the
@@ -329,12 +321,10 @@ def test_f16x2_vs_exact_f32_mfma_random_geometries(vgg_weights, monkeypatch, geo
     c, s = _levels(h, w, nlev, 1), _levels(hs, ws, nlev, 2)
     x = dev(cpu_ref.prepare_img((0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(h, w, seed=9)).astype(np.float32)))
     res = []
-    for env in ({"NST_CONV": "f32", "NST_BATCH": "0", "NST_H2_BAND_ROWS": "0"},
-                {"NST_CONV": "f16x2", "NST_BATCH": "1", "NST_H2_BAND_ROWS": "0"},
-                {"NST_CONV": "f16x2", "NST_BATCH": "0", "NST_H2_BAND_ROWS": "16"}):      # per-level launches in 16-row bands
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        e = StyleEngine(vgg_weights, 0)
+    for opts in (dict(conv_mode="f32", batched=False, h2_band_rows=0),
+                 dict(conv_mode="f16x2", batched=True, h2_band_rows=0),
+                 dict(conv_mode="f16x2", batched=False, h2_band_rows=16)):      # per-level launches in 16-row bands
+        e = StyleEngine(vgg_weights, 0, **opts)
         try:
             _setup(e, c, s)
             g, l = e.closure(x, 1e3, 4e5, 1e2)
@@ -346,10 +336,43 @@ def test_f16x2_vs_exact_f32_mfma_random_geometries(vgg_weights, monkeypatch, geo
         np.testing.assert_allclose(l1[-1], l0[-1], rtol=1e-5)
         np.testing.assert_allclose(l1[:-1].reshape(nlev, 4)[:, 0], l0[:-1].reshape(nlev, 4)[:, 0], rtol=2e-5)
         assert np.isfinite(g1).all()
-        assert rel_l2(g1, g0) < GRAD_RTOL
+        assert_grad_close(g1, g0, f"geometry {geo}")
     # the banded per-level launches compute what the batched launches compute
     np.testing.assert_allclose(res[2][1], res[1][1], rtol=1e-6)
     assert rel_l2(res[2][0], res[1][0]) < 1e-5
+
+
+@pytest.mark.parametrize("trial", [0, 1, 2, 3])
+def test_hostile_operand_scales_vs_oracle(trial):
+    """The f16x2 arithmetic rests on ONE power-of-two scale per tensor; its error depends on operand statistics.  Here
+    they are hostile: per-layer weight scales between 2^-6 and 2^6 (consecutive layers compensate, so activations and
+    gradients swing over many binades from layer to layer), biases of sigma = 3, an image with outliers far outside
+    [0, 1].  The default closure - and the library's exact-f32-MFMA mode beside it - against the ORACLE (torch fp32 on
+    the CPU) on the same weights: losses 1e-5, gradients under equal decisions 2e-5, per term."""
+    from artstyletransfer_amd.engine import StyleEngine
+    rng = np.random.RandomState(7 + trial)
+    base = cpu_ref.synthetic_vgg19_weights()
+    scales = 2.0 ** rng.randint(-6, 7, size=len(base))
+    scales[1::2] = 1.0 / scales[0::2][:len(scales[1::2])]          # keep the product of consecutive pairs at 1
+    w = [(wt * float(sc), torch.from_numpy(rng.normal(0, 3.0, tuple(b.shape)).astype(np.float32)))
+         for (wt, b), sc in zip(base, scales)]
+    h, wd, nlev = 96, 144, 2
+    img = cpu_ref.synthetic_image(h, wd, seed=11 + trial)
+    img[rng.randint(0, h, 30), rng.randint(0, wd, 30)] = rng.choice([0.0, 1.0, 3.0, -2.0], size=(30, 1))     # outliers
+    c = [img, _levels(h, wd, 2, 11 + trial)[1]]
+    s = [np.ascontiguousarray(a[:, ::-1]) for a in c]
+    x_img = (0.6 * img + 0.4 * img[::-1]).astype(np.float32)
+    xt = cpu_ref.prepare_img(x_img)
+    tg = oracle_targets(c, s, w)
+    for opts in (dict(), dict(conv_mode="f32", batched=False)):
+        e = StyleEngine(w, 0, **opts)
+        try:
+            _setup(e, c, s)
+            # near-ties are judged against the layer's rms, and sigma-3 biases put a larger share of the units there
+            closure_vs_oracle_under_equal_decisions(e, xt, tg, w, f"hostile scales {trial} log2 {np.log2(scales).astype(int).tolist()} {opts}",
+                                                    terms=TERMS[:3], cap=5e-2)
+        finally:
+            e.close()
 
 
 @pytest.mark.parametrize("H0,W0,world", [(384, 256, 2), (384, 256, 3), (512, 208, 4), (390, 250, 2), (471, 183, 3)])
@@ -393,7 +416,7 @@ def test_stripe_closure_adds_up_to_the_unsharded_closure(eng, vgg_weights, H0, W
         np.testing.assert_array_equal(r, rows[0])
         assert float(r[-1]) == pytest.approx(float(l_ref[-1]), rel=1e-5)
         check_rows(r[:4].reshape(1, 4), l_ref[:4].reshape(1, 4), 2e-5)
-    assert rel_l2(grad.cpu().numpy(), g_ref.cpu().numpy()) < GRAD_RTOL
+    assert_grad_close(grad.cpu().numpy(), g_ref.cpu().numpy(), f"stripes {H0}x{W0}/{world}")
 
 
 def test_closure_finite_difference(eng, vgg_weights):
@@ -410,138 +433,6 @@ def test_closure_finite_difference(eng, vgg_weights):
     fd = (float(lp[-1].cpu()) - float(lm[-1].cpu())) / (2 * eps)
     an = float((grad.double() * d.double()).sum().cpu())
     assert fd == pytest.approx(an, rel=2e-2)
-
-
-# ---------------------------------------------------------------- optimisers
-def test_adam_trajectory_vs_reference(eng, vgg_weights, golden):
-    from artstyletransfer_amd.engine import PixelOptimizer
-    fx = golden("traj_adam_64x96_L1_12")
-    c, s = _levels(64, 96, 2, 1), _levels(64, 96, 2, 2)
-    _setup(eng, c, s)
-    x = dev(cpu_ref.prepare_img(c[0]))
-    opt = PixelOptimizer(eng, "adam")
-    rows = []
-    for k in range(12):
-        info, r = opt.step(x, 1e3, 4e5, 1e2)
-        assert info.closures == 1 and info.total_closures == k + 1
-        rows.append(r[0, :-1].reshape(2, 4))
-        if k == 0:
-            img = eng.unprepare_img(x).cpu().numpy()
-            np.testing.assert_allclose(img, fx["after_1"], rtol=0, atol=2e-5)
-    # free-running: Adam's first steps are sign-like (m/sqrt(v) = +-1), so a gradient entry whose sign
-    # differs (ReLU-decision flips, see GRAD_RTOL) moves that pixel by +-lr; on this tiny image the loss
-    # rows stay within 1e-2 of the reference's (measured 3.7e-3 at worst), the first step within 1e-5
-    check_rows(np.array(rows)[:1], fx["rows"][:1], 2e-5)
-    check_rows(np.array(rows), fx["rows"], 1e-2)
-    # pixel trajectories separate chaotically (measured median |diff| 2.7e-3 in [0,1] units after 12 steps);
-    # the images must still be the same picture
-    assert np.mean(np.abs(eng.unprepare_img(x).cpu().numpy() - fx["final"])) < 2e-2
-    assert info.lr == pytest.approx(10.0 * 0.999 ** 12, rel=1e-6)
-    opt.close()
-
-
-def test_adam_teacher_forced(eng, vgg_weights):
-    """The oracle drives x; at every x_k the HIP closure must reproduce loss and gradient, and one HIP Adam
-    update from the oracle's (x, m, v) state must land on the oracle's next x."""
-    c, s = _levels(64, 96, 2, 1), _levels(64, 96, 2, 2)
-    _setup(eng, c, s)
-    tg = [cpu_ref.LevelTargets(cpu_ref.prepare_img(ci), cpu_ref.prepare_img(si), vgg_weights) for ci, si in zip(c, s)]
-    x = cpu_ref.prepare_img(c[0]).contiguous()
-    adam = cpu_ref.AdamState(x.numel())
-    lr = 10.0
-    for k in range(6):
-        lr *= 0.999
-        loss, grad, rows = cpu_ref.closure_eval(x, tg, vgg_weights, 1e3, 4e5, 1e2)
-        g_hip, l_hip = eng.closure(dev(x), 1e3, 4e5, 1e2)
-        assert float(l_hip[-1].cpu()) == pytest.approx(float(loss), rel=1e-5), k
-        assert rel_l2(g_hip.cpu().numpy(), grad.numpy()) < GRAD_RTOL, k
-        xf = x.reshape(-1)
-        adam.update(xf, grad.reshape(-1), lr)
-        x = xf.view(x.shape)
-
-
-@pytest.mark.parametrize("tag,max_eval", [("shipped", 1), ("legacy", 26)])
-def test_lbfgs_trajectory_vs_reference(eng, vgg_weights, golden, tag, max_eval):
-    from artstyletransfer_amd.engine import PixelOptimizer
-    fx = golden(f"traj_lbfgs_128x192_L1_{tag}")
-    c, s = _levels(128, 192, 2, 1), _levels(128, 192, 2, 2)
-    _setup(eng, c, s)
-    x = dev(cpu_ref.prepare_img(c[0]))
-    opt = PixelOptimizer(eng, "lbfgs", lbfgs_max_eval=max_eval)
-    rows, steps, moved = [], [], []
-    total = 0
-    while total < 40:
-        info, r = opt.step(x, 1e3, 4e5, 1e2)
-        total = info.total_closures
-        steps.append(total)
-        moved.append(bool(info.accepted))
-        rows.extend(list(r[:, :-1].reshape(-1, 2, 4)))
-    rows = np.array(rows)
-    if tag == "shipped":
-        # identical closure count per step and identical accept/reject sequence
-        assert steps == list(fx["steps"])
-        assert moved == list(fx["moved"])
-        check_rows(rows, fx["rows"], 1e-3)
-    else:
-        # a real line search amplifies rounding differences (the CPU oracle itself drifts ~0.5%
-        # from the reference after 40 closures when one gradient ulp differs): compare the
-        # first step (its interpolated trial points already differ by 2e-3) and the final loss level only
-        n0 = int(fx["steps"][0])
-        assert steps[0] == n0
-        check_rows(rows[:2], fx["rows"][:2], 2e-5)
-        check_rows(rows[:n0], fx["rows"][:n0], 1e-2)
-        ref_last = fx["rows"][int(fx["steps"][-2])][:, 0].sum()
-        mine_last = rows[steps[-2]][:, 0].sum() if steps[-2] < len(rows) else rows[-1][:, 0].sum()
-        assert mine_last == pytest.approx(ref_last, rel=0.05)
-    opt.close()
-
-
-@pytest.mark.parametrize("gram", ["1", "0"])
-@pytest.mark.parametrize("h,w", [(35, 51), (64, 96)])
-def test_lbfgs_update_arithmetic_teacher_forced(eng, vgg_weights, monkeypatch, h, w, gram):
-    """The optimiser arithmetic alone - two-loop recursion on the device (one fused launch per history pair), line
-    search, curvature pairs - against the oracle's L-BFGS driven by the SAME closure (the HIP one), so that only
-    the update arithmetic can differ: 25-evaluation line search, lr 1, so that steps are accepted and the history
-    grows.  35 x 51 gives n = 5355 (n mod 4 = 3: the scalar tails of the vector kernels).  gram = "1": the default
-    direction from inner products (one multi-dot and one multi-axpy pass over the history); "0": the sequential
-    recursion, one fused launch per pair."""
-    from artstyletransfer_amd.engine import PixelOptimizer
-    monkeypatch.setenv("NST_LBFGS_GRAM", gram)
-    c, s = _levels(h, w, 1, 1), _levels(h, w, 1, 2)
-    _setup(eng, c, s)
-    x0 = cpu_ref.prepare_img((0.6 * c[0] + 0.4 * s[0]).astype(np.float32)).contiguous()
-    cw, sw, tvw = 1e3, 4e5, 1e2
-
-    def hip_closure(flat):
-        g, l = eng.closure(dev(flat.view_as(x0)), cw, sw, tvw)
-        return float(l[-1].cpu()), g.cpu().reshape(-1).clone()
-
-    steps = 10
-    # oracle optimiser on the HIP closure
-    st = cpu_ref.LbfgsState(max_eval=26)
-    xo = x0.clone().reshape(-1)
-    lr, ref_losses, ref_evals = 1.0, [], []
-    for _ in range(steps):
-        before = st.func_evals
-        ref_losses.append(cpu_ref.lbfgs_step(st, xo, lr, hip_closure))
-        ref_evals.append(st.func_evals - before)
-        lr *= 0.999 ** ref_evals[-1]
-    # HIP optimiser
-    xh = dev(x0.clone())
-    opt = PixelOptimizer(eng, "lbfgs", 1.0, 26)
-    losses, evals = [], []
-    for _ in range(steps):
-        info, _rows = opt.step(xh, cw, sw, tvw)
-        losses.append(float(info.loss)); evals.append(int(info.closures))
-    opt.close()
-    assert evals == ref_evals                                # the same line-search decisions in every step
-    assert len(st.old_dirs) >= steps - 2                     # the history did grow
-    # The dot products differ in rounding (torch: fp32 pairwise; here: fp32 per lane, double across lanes) and the
-    # line search amplifies that from step to step: measured 5e-6 / 6e-7 / 1.2e-5 in steps 2-4, 3e-3 by step 10
-    # (35 x 51); below 2e-4 throughout at 64 x 96.
-    np.testing.assert_allclose(losses[:4], ref_losses[:4], rtol=5e-5)
-    np.testing.assert_allclose(losses, ref_losses, rtol=1e-2)
-    assert rel_l2(xh.cpu().numpy().reshape(-1), xo.numpy()) < 5e-2
 
 
 def test_level_sharded_closure_adds_up(eng, vgg_weights):
@@ -563,10 +454,10 @@ def test_level_sharded_closure_adds_up(eng, vgg_weights):
     assert float(parts[1][1][0]) == 0.0 and float(parts[0][1][4]) == 0.0      # rows of foreign levels are zeros
 
 
-@pytest.mark.parametrize("levels_num", [3, 5])
+@pytest.mark.parametrize("levels_num", [3, 4, 5])
 def test_full_size_job_properties(monkeypatch, levels_num):
-    """BASELINE config 3 (L=2: 1024x1536 top level, three levels, noise init) at full size, where the oracle takes
-    minutes per closure, and the largest job tried (L=4: 4096x6144, five levels, ~45 GB of activations, level-0
+    """BASELINE config 3 (L=2: 1024x1536 top level, three levels, noise init) and config 4's workload (L=3: 2048x3072,
+    four levels) at full size, where the oracle takes minutes per closure, and the largest job tried (L=4: 4096x6144, five levels, ~45 GB of activations, level-0
     tensors beyond 4 GiB that take the 64-bit-addressed code paths): size-independent properties instead.  (1) the closure is idempotent - bitwise the same
     gradient and loss rows when evaluated twice; (2) it is additive over levels - disjoint level subsets sum to
     the full closure; (3) each level's row obeys total = cw*content + sw*style + tvw*tv and the grand total is the
@@ -606,14 +497,12 @@ def test_full_size_job_properties(monkeypatch, levels_num):
         assert (fp - fm) / (2 * eps) == pytest.approx(an, rel=2e-2)
     finally:
         eng.close()
-    monkeypatch.setenv("NST_CONV", "f32")
-    monkeypatch.setenv("NST_BATCH", "0")
-    other, x2, _, _ = bench.build_job(n, 0, 0)
+    other, x2, _, _ = bench.build_job(n, 0, 0, conv_mode="f32", batched=False)
     try:
         assert other.conv_mode() == "f32" and torch.equal(x2, x)
         g2, l2 = other.closure(x2, cw, sw, tvw)
         np.testing.assert_allclose(l2.cpu().numpy(), l0.cpu().numpy(), rtol=1e-5)
-        assert rel_l2(g2.cpu().numpy(), g0.cpu().numpy()) < GRAD_RTOL
+        assert_grad_close(g2.cpu().numpy(), g0.cpu().numpy(), f"full size levels_num={n}: f16x2 vs f32")
     finally:
         other.close()
 
@@ -657,8 +546,7 @@ def test_stripe_and_mode_errors_are_reported(vgg_weights, monkeypatch):
         e.window_begin(x, 16, 48, 128)              # a bottom stripe may end on any row: fine
     finally:
         e.close()
-    monkeypatch.setenv("NST_CONV", "bf16x3")
-    e = StyleEngine(vgg_weights, 0)
+    e = StyleEngine(vgg_weights, 0, conv_mode="bf16x3")
     try:
         e.configure(1, 64, 48)
         e.set_targets(0, x, x)
@@ -669,6 +557,8 @@ def test_stripe_and_mode_errors_are_reported(vgg_weights, monkeypatch):
     monkeypatch.setenv("NST_CONV", "fp8")
     with pytest.raises(NstError, match="NST_CONV"):
         StyleEngine(vgg_weights, 0)
+    with pytest.raises(NstError, match="conv_mode"):
+        StyleEngine(vgg_weights, 0, conv_mode="fp8")
 
 
 # ---------------------------------------------------------------- job set-up on the device (rows f-1 / f-2)

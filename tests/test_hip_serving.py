@@ -1,0 +1,227 @@
+"""GPU: behaviour of the path as a long-lived service (the reference's Executor keeps jobs coming: task_executor.py) -
+no memory left behind by jobs that end early, jobs that share a GPU do not disturb each other's results, the real-weights
+loader feeds the device network - and the RCCL communicator behind the C ABI."""
+import asyncio
+import os
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cpu_ref
+from hip_helpers import CW, SW, TVW, assert_grad_close, check_rows, dev, levels, oracle_targets, rel_l2, report, setup
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_bytes():
+    torch.cuda.synchronize()
+    return torch.cuda.mem_get_info(0)[0]
+
+
+def test_generator_closed_early_frees_the_optimiser(vgg_weights, monkeypatch):
+    """A consumer that stops after two yields (aclose at the yield), with L-BFGS steps accepted so that curvature pairs
+    exist: the optimiser's buffers - gradient, direction, the whole history pool (202 vectors of 12*H*W bytes) - and the
+    engine's workspace must be returned; device memory comes back to where it was before the job."""
+    from artstyletransfer_amd import neural_nets
+    import neural_style_transfer as nst
+    neural_nets.set_weights(vgg_weights)
+    monkeypatch.setattr(nst, "LBFGS_MAX_EVAL", 26, raising=False)
+    import artstyletransfer_amd.neural_style_transfer as impl
+    monkeypatch.setattr(impl, "LBFGS_MAX_EVAL", 26)
+    c, s = levels(256, 384, 1, 1), levels(256, 384, 1, 2)
+
+    async def run(stop_after):
+        job = nst.NeuralStyleTransfer(torch.device("cuda", 0), "vgg19", s, "lbfgs")
+        gen = job.process(c, c[0], 1.0, 400, CW, SW, TVW, "leak")
+        seen = 0
+        async for _img, _step in gen:
+            seen += 1
+            if seen == stop_after:
+                break
+        await gen.aclose()
+        return seen
+
+    asyncio.run(run(1))                       # warm-up: code objects, pinned buffers, the caching allocator's pools
+    torch.cuda.empty_cache()
+    base = _free_bytes()
+    held = []
+    for _ in range(3):
+        assert asyncio.run(run(2)) == 2
+        torch.cuda.empty_cache()
+        held.append(base - _free_bytes())
+    pool = 202 * 12 * 256 * 384               # what one leaked optimiser would hold at least
+    report(f"early-closed jobs: device bytes not returned after each of 3 jobs {held} (one history pool = {pool})")
+    assert max(held) < pool // 8
+
+
+def test_failed_step_frees_the_optimiser(vgg_weights, monkeypatch):
+    """A step that raises inside the pool thread: the job dies with that exception and leaves nothing on the device."""
+    from artstyletransfer_amd import engine, neural_nets
+    import neural_style_transfer as nst
+    neural_nets.set_weights(vgg_weights)
+    c, s = levels(128, 192, 1, 1), levels(128, 192, 1, 2)
+    real_step = engine.PixelOptimizer.step
+    calls = {"n": 0}
+
+    def failing_step(self, *a, **k):
+        calls["n"] += 1
+        if calls["n"] % 2 == 0:
+            raise RuntimeError("injected failure")
+        return real_step(self, *a, **k)
+
+    async def run():
+        job = nst.NeuralStyleTransfer(torch.device("cuda", 0), "vgg19", s, "adam")
+        async for _ in job.process(c, c[0], 10.0, 50, CW, SW, TVW, "fail"):
+            pass
+
+    monkeypatch.setattr(engine.PixelOptimizer, "step", failing_step)
+    with pytest.raises(RuntimeError, match="injected"):
+        asyncio.run(run())
+    torch.cuda.empty_cache()
+    base = _free_bytes()
+    for _ in range(2):
+        with pytest.raises(RuntimeError, match="injected"):
+            asyncio.run(run())
+    torch.cuda.empty_cache()
+    assert base - _free_bytes() < 4 << 20
+
+
+def test_two_jobs_on_one_gpu_do_not_disturb_each_other(vgg_weights):
+    """Two jobs per GPU is the scheduler's default (config.simultaneous_tasks_count).  While job A steps on its own
+    stream from its own thread, the main thread creates, configures, runs and destroys other contexts on the same GPU
+    (what the Executor does when a job ends and the next starts): A's loss rows and final image must be bitwise those of
+    A running alone.  nst_job_configure / nst_ctx_destroy / nst_opt_destroy wait on the context's own event and
+    streams, not on the device."""
+    from artstyletransfer_amd.engine import PixelOptimizer, StyleEngine
+    c, s = levels(256, 384, 2, 1), levels(256, 384, 2, 2)
+    c2, s2 = levels(128, 192, 1, 3), levels(128, 192, 1, 4)
+
+    def job_a(out, churn_flag):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            e = StyleEngine(vgg_weights, 0)
+            setup(e, c, s)
+            x = dev(cpu_ref.prepare_img(c[0]))
+            opt = PixelOptimizer(e, "lbfgs", 1.0, 26)
+            rows = []
+            for _ in range(12):
+                info, r = opt.step(x, CW, SW, TVW)
+                rows.append(r.copy())
+            st.synchronize()
+            out["rows"] = np.concatenate(rows)
+            out["x"] = x.cpu()
+            churn_flag.set()
+            opt.close()
+            e.close()
+
+    alone, done = {}, threading.Event()
+    job_a(alone, done)
+    shared, done = {}, threading.Event()
+    t = threading.Thread(target=job_a, args=(shared, done))
+    t.start()
+    churned = 0
+    while not done.is_set():
+        e = StyleEngine(vgg_weights, 0)
+        setup(e, c2, s2)
+        opt = PixelOptimizer(e, "adam")
+        x2 = dev(cpu_ref.prepare_img(c2[0]))
+        opt.step(x2, CW, SW, TVW)
+        e.configure(1, 96, 160)               # re-configuration frees and re-allocates the workspace
+        opt.close()
+        e.close()
+        churned += 1
+    t.join()
+    report(f"two jobs on one GPU: {churned} contexts created and destroyed while the other job made 12 L-BFGS steps")
+    assert churned >= 1
+    assert np.array_equal(alone["rows"], shared["rows"])
+    assert torch.equal(alone["x"], shared["x"])
+
+
+def test_real_weights_path_end_to_end(tmp_path, monkeypatch, vgg_weights):
+    """neural_nets.load_weights (replaces the pretrained fetch of neural_nets.py:19) -> Vgg19.forward on the device: a
+    torchvision-style state dict with NON-ZERO biases written to a file, found through NST_VGG19_WEIGHTS, must give the
+    oracle's six feature maps for those weights."""
+    from artstyletransfer_amd import neural_nets
+    from test_host_api import _fake_torchvision_state_dict
+    sd = _fake_torchvision_state_dict()
+    # rescale so that activations neither vanish nor explode through 13 layers (the loader does not care)
+    for k in list(sd):
+        if k.startswith("features") and k.endswith("weight"):
+            w = sd[k]
+            sd[k] = (w - w.mean()) / w.std() * (2.0 / (w.shape[0] * 9)) ** 0.5
+        elif k.startswith("features") and k.endswith("bias"):
+            sd[k] = (sd[k] - sd[k].mean()) * 2.0
+    path = tmp_path / "vgg19-fake.pth"
+    torch.save(sd, path)
+    monkeypatch.setenv("NST_VGG19_WEIGHTS", str(path))
+    neural_nets.set_weights([])                       # drop cached engines
+    monkeypatch.setattr(neural_nets, "_weights_cache", None)
+    try:
+        net = neural_nets.Vgg19().to("cuda:0").eval()
+        ws = neural_nets.load_weights()
+        assert all(float(b.abs().max()) > 0 for _, b in ws)
+        x = cpu_ref.prepare_img(cpu_ref.synthetic_image(48, 80, seed=3))
+        outs = net(dev(x))
+        assert outs._fields == ("relu1_1", "relu2_1", "relu3_1", "relu4_1", "conv4_2", "relu5_1")
+        ref = cpu_ref.vgg19_features(x, ws)
+        for i, (o, r) in enumerate(zip(outs, ref)):
+            assert rel_l2(o.cpu().numpy(), r.numpy()) < 3e-6, i
+    finally:
+        neural_nets.set_weights(vgg_weights)
+
+
+# ---------------------------------------------------------------- communicator
+def test_comm_single_rank_and_sharded_driver(vgg_weights):
+    """nst_comm_* on one rank (librccl resolved at run time, ncclCommInitRank with world = 1, all-reduce on the job's stream)
+    and the optimiser driver with the collective behind the ABI (nst_opt_shard_levels_comm: gradient + loss row packed
+    into ONE buffer, one ncclAllReduce per closure): with a world of one the trajectory must be bitwise the unsharded one."""
+    from artstyletransfer_amd.engine import Communicator, PixelOptimizer, StyleEngine
+    comm = Communicator(0, 0, 1, Communicator.unique_id())
+    try:
+        t = torch.arange(1000, dtype=torch.float32, device="cuda:0")
+        comm.allreduce_sum(t)
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), torch.arange(1000, dtype=torch.float32))
+        assert comm.info()[:3] == (0, 1, 1)
+        c, s = levels(128, 192, 3, 1), levels(128, 192, 3, 2)
+        res = []
+        for use_comm in (False, True):
+            e = StyleEngine(vgg_weights, 0)
+            setup(e, c, s)
+            x = dev(cpu_ref.prepare_img((0.7 * c[0] + 0.3 * s[0]).astype(np.float32)))
+            opt = PixelOptimizer(e, "lbfgs", 1.0, 26)
+            if use_comm:
+                opt.shard_levels_comm(comm)
+            rows = []
+            for _ in range(4):
+                info, r = opt.step(x, CW, SW, TVW)
+                rows.append(r.copy())
+            res.append((np.concatenate(rows), x.cpu()))
+            opt.close()
+            e.close()
+        assert np.array_equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        rank, world, calls, nbytes = comm.info()
+        assert calls == 1 + len(res[1][0])               # one collective per closure
+        assert (nbytes - 4000.0) / (calls - 1) == 4.0 * (((3 * 128 * 192 + 63) // 64) * 64 + 13)   # gradient + loss row, packed
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("mode", ["levels", "stripes"])
+def test_sharded_job_over_rccl_matches_the_unsharded_job(mode):
+    """Two ranks on two GPUs over RCCL (skipped on a one-GPU box): tools/check_sharded_opt.py runs the optimiser sharded
+    over the ranks and unsharded, and asserts the same accept / reject sequence and loss rows."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", NST_SYNTHETIC_WEIGHTS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29517", os.path.join(root, "tools", "check_sharded_opt.py"), mode, "--backend", "nccl",
+           "--c-abi-comm" if mode == "levels" else "--torch-comm"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "SHARDED == UNSHARDED" in out.stdout

@@ -32,7 +32,24 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} is declared in include/nst_hip.h but not exported"
     # the binding table covers the header exactly
     assert sorted(_lib.SYMBOLS) == names
-    assert _lib.load().nst_version() >= 100
+    assert _lib.load().nst_version() >= 200
+
+
+def test_options_struct_matches_the_header():
+    """The ctypes mirror of nst_options / nst_step_info has the header's fields in the header's order, and
+    nst_options_default fills every field with -1 (= environment, then default)."""
+    from artstyletransfer_amd import _lib
+    text = open(os.path.join(ROOT, "include", "nst_hip.h")).read()
+    body = re.search(r"typedef struct nst_options \{(.*?)\} nst_options;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    assert re.findall(r"int\s+([a-z0-9_]+);", body) == [f[0] for f in _lib.Options._fields_]
+    body = re.search(r"typedef struct nst_step_info \{(.*?)\} nst_step_info;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    assert re.findall(r"(?:int|float)\s+([a-z0-9_]+);", body) == [f[0] for f in _lib.StepInfo._fields_]
+    o = _lib.Options()
+    _lib.load().nst_options_default(ctypes.byref(o))
+    assert o.struct_size == ctypes.sizeof(_lib.Options)
+    assert [getattr(o, f[0]) for f in _lib.Options._fields_[1:]] == [-1] * 6
 
 
 def test_no_gpu_is_an_error_not_a_fallback(vgg_weights):
@@ -87,6 +104,15 @@ def test_config_surface():
     assert config.Config(levels_num=3, iters_num=10).levels_num == 3
     with pytest.raises(TypeError):
         config.Config(bogus=1)
+    # positional, in the reference's order (config.py:5-18)
+    p = config.Config(1.0, 2.0, 3.0, "adam", "vgg19", "random", 4, 7)
+    assert (p.content_weight, p.style_weight, p.tv_weight, p.optimizer, p.init_method, p.levels_num, p.iters_num) == \
+        (1.0, 2.0, 3.0, "adam", "random", 4, 7)
+    assert p.noise_factor == 0.95
+    with pytest.raises(TypeError):
+        config.Config(1.0, content_weight=2.0)
+    with pytest.raises(TypeError):
+        config.Config(*range(14))
 
 
 def test_module_and_signature_surface():
@@ -125,11 +151,18 @@ def test_module_and_signature_surface():
     del net
 
 
-def test_vgg19_attributes(monkeypatch):
+def test_vgg19_attributes(monkeypatch, tmp_path):
     import warnings
     from artstyletransfer_amd import neural_nets
     monkeypatch.delenv("NST_VGG19_WEIGHTS", raising=False)
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path))              # no checkpoint anywhere we look
+    monkeypatch.setenv("HOME", str(tmp_path))
     monkeypatch.setattr(neural_nets, "_weights_cache", None)
+    monkeypatch.delenv("NST_SYNTHETIC_WEIGHTS", raising=False)
+    if neural_nets.find_checkpoint() is None:
+        with pytest.raises(FileNotFoundError, match="NST_SYNTHETIC_WEIGHTS"):     # no silent random weights
+            neural_nets.Vgg19()
+    monkeypatch.setenv("NST_SYNTHETIC_WEIGHTS", "1")
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         net = neural_nets.Vgg19()
@@ -139,6 +172,66 @@ def test_vgg19_attributes(monkeypatch):
     assert len(list(net.parameters())) == 26
     assert sum(p.numel() for p in net.parameters()) == 12944960
     assert net.to("cpu").eval() is net
+
+
+def _fake_torchvision_state_dict(seed=5):
+    """A state dict with torchvision vgg19's keys and shapes (features.N.weight/bias for the 16 convs, the classifier)
+    and values that identify their slot: non-zero biases, a distinct mean per layer."""
+    import torch
+    cfg = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+    g = torch.Generator().manual_seed(seed)
+    sd, cin, idx = {}, 3, 0
+    for v in cfg:
+        if v == "M":
+            idx += 1
+            continue
+        sd[f"features.{idx}.weight"] = torch.randn(v, cin, 3, 3, generator=g) * 0.05 + 0.001 * idx
+        sd[f"features.{idx}.bias"] = torch.randn(v, generator=g) * 0.5 + idx
+        cin = v
+        idx += 2
+    sd["classifier.0.weight"] = torch.zeros(8, 8)
+    return sd
+
+
+def test_load_weights_from_a_torchvision_state_dict(monkeypatch, tmp_path):
+    """neural_nets.load_weights (replaces the pretrained fetch of neural_nets.py:19): explicit path, the reference's
+    TORCH_HOME cache location, order and shapes of the 13 pairs, rejection of a wrong file."""
+    import torch
+    from artstyletransfer_amd import neural_nets
+    sd = _fake_torchvision_state_dict()
+    conv_idx = [0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 23, 25, 28]            # SURVEY A.3
+    assert sorted(int(k.split(".")[1]) for k in sd if k.endswith(".weight") and k.startswith("features"))[:13] == conv_idx
+
+    def check(ws):
+        assert len(ws) == 13
+        for (w, b), i in zip(ws, conv_idx):
+            assert w.dtype == torch.float32 and torch.equal(w, sd[f"features.{i}.weight"])
+            assert torch.equal(b, sd[f"features.{i}.bias"]) and float(b.abs().min()) >= 0.0 and float(b.mean()) > i - 1
+
+    path = tmp_path / "my_vgg19.pth"
+    torch.save(sd, path)
+    monkeypatch.setattr(neural_nets, "_weights_cache", None)
+    monkeypatch.setenv("NST_VGG19_WEIGHTS", str(path))
+    check(neural_nets.load_weights())
+    # where the reference's own download would have cached it: $TORCH_HOME/hub/checkpoints/vgg19-<hash>.pth
+    monkeypatch.delenv("NST_VGG19_WEIGHTS")
+    monkeypatch.setattr(neural_nets, "_weights_cache", None)
+    ck = tmp_path / "home" / "hub" / "checkpoints"
+    ck.mkdir(parents=True)
+    torch.save(sd, ck / "vgg19-dcbb9e9d.pth")
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path / "home"))
+    assert neural_nets.find_checkpoint() == str(ck / "vgg19-dcbb9e9d.pth")
+    check(neural_nets.load_weights())
+    # a state dict of another network is refused, not mis-read
+    bad = dict(sd)
+    del bad["features.28.bias"]
+    with pytest.raises(KeyError, match="features.28.bias"):
+        neural_nets.state_dict_to_weights(bad)
+    bad = dict(sd)
+    bad["features.5.weight"] = torch.zeros(128, 32, 3, 3)
+    with pytest.raises(ValueError, match="features.5"):
+        neural_nets.state_dict_to_weights(bad)
+    monkeypatch.setattr(neural_nets, "_weights_cache", None)
 
 
 # ---------------------------------------------------------------- host image preparation

@@ -83,6 +83,33 @@ def test_closure_small(golden, vgg_weights, name, nlev):
     ref = fx["grad"]
     rel_l2 = np.linalg.norm(grad.numpy() - ref) / np.linalg.norm(ref)
     assert rel_l2 < 1e-6
+    # every loss term alone: (cw,0,0), (0,sw,0), (0,0,tvw) through the reference's LossBuilder
+    tg = [cpu_ref.LevelTargets(cpu_ref.prepare_img(fx[f"content{i}"]), cpu_ref.prepare_img(fx[f"style{i}"]), vgg_weights)
+          for i in range(nlev)]
+    for tag, wts in (("c", (1e3, 0.0, 0.0)), ("s", (0.0, 4e5, 0.0)), ("tv", (0.0, 0.0, 1e2))):
+        loss, grad, _ = cpu_ref.closure_eval(cpu_ref.prepare_img(fx["x_img"]), tg, vgg_weights, *wts)
+        assert float(loss) == pytest.approx(float(fx[f"total_{tag}"]), rel=1e-6)
+        ref = fx[f"grad_{tag}"]
+        assert np.linalg.norm(grad.numpy() - ref) / np.linalg.norm(ref) < 1e-6, tag
+
+
+def test_forced_decisions_are_a_no_op_on_own_decisions(vgg_weights):
+    """cpu_ref.Decisions taken from the evaluation's own activations must reproduce that evaluation bit for bit (the
+    GPU tests hand the DEVICE pass's decisions to the oracle; this pins the mechanism itself)."""
+    c, s = _levels(48, 80, 2, 1), _levels(40, 56, 2, 2)
+    tg = [cpu_ref.LevelTargets(cpu_ref.prepare_img(a), cpu_ref.prepare_img(b), vgg_weights) for a, b in zip(c, s)]
+    xt = cpu_ref.prepare_img((0.5 * c[0] + 0.5 * cpu_ref.synthetic_image(48, 80, 9)).astype(np.float32))
+    rec = []
+    loss, grad, rows = cpu_ref.closure_eval(xt, tg, vgg_weights, 1e3, 4e5, 1e2, record=rec)
+    assert len(rec) == 2 and len(rec[0]) == 13
+    dec = [cpu_ref.Decisions([torch.relu(p) for p in r]) for r in rec]
+    loss2, grad2, rows2 = cpu_ref.closure_eval(xt, tg, vgg_weights, 1e3, 4e5, 1e2, decisions=dec)
+    assert float(loss2) == float(loss) and rows2 == rows
+    assert torch.equal(grad2, grad)
+    # flipping ONE deep unit changes the gradient over its receptive field - the effect the forced mode removes
+    dec[0].relu[9][0, 5, 2, 3] = ~dec[0].relu[9][0, 5, 2, 3]
+    _, grad3, _ = cpu_ref.closure_eval(xt, tg, vgg_weights, 1e3, 4e5, 1e2, decisions=dec)
+    assert not torch.equal(grad3, grad)
 
 
 def _levels(h, w, nlev, seed):
@@ -153,3 +180,23 @@ def test_adam_trajectory_L0_config1(golden, vgg_weights):
     rows = np.array([r["rows"] for r in rec])
     np.testing.assert_allclose(rows, fx["rows"], rtol=1e-4)
     _check_summary(torch.from_numpy(last), fx, "final", rtol=0, atol=5e-4)
+
+
+def test_config2_geometry_prefixes(golden, vgg_weights):
+    """The fixtures of BASELINE config 2's pyramid (768x512 + 384x256) hold hundreds of closures of the reference (25 min
+    of CPU to make); the oracle is held to their first closures here (the whole runs are the GPU tests' reference):
+    Adam 3 iterations, L-BFGS as shipped 4 closures."""
+    c, s = _levels(512, 768, 2, 1), _levels(512, 768, 2, 2)
+    fx = golden("traj_adam_512x768_L1_100")
+    rec = []
+    for img, step in cpu_ref.run_process(c, s, c[0], vgg_weights, "adam", 3, record=rec):
+        if step == 1:
+            _check_summary(torch.from_numpy(img), fx, "after_1", rtol=0, atol=1e-5)
+    np.testing.assert_allclose(np.array([r["rows"] for r in rec]), fx["rows"][:3], rtol=2e-5)
+    fx = golden("traj_lbfgs_512x768_L1_500")
+    rec, moved, prev = [], [], c[0]
+    for img, step in cpu_ref.run_process(c, s, c[0], vgg_weights, "lbfgs", 4, record=rec):
+        moved.append(bool(np.any(img != prev)))
+        prev = img
+    assert moved == list(fx["moved"][:2]) and list(fx["steps"][:2]) == [2, 4]
+    np.testing.assert_allclose(np.array([r["rows"] for r in rec]), fx["rows"][:4], rtol=1e-4)

@@ -1,28 +1,90 @@
-"""GPU rehearsal (1 GPU, gloo, 2 ranks sharing cuda:0, or 1 rank): loss of every closure of the first optimiser steps."""
-import os, sys
+"""The optimiser sharded over the ranks against the same optimiser unsharded: accept / reject sequence and loss rows.
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node=2 --master-addr 127.0.0.1 --master-port 29517 \
+        tools/check_sharded_opt.py levels|stripes [--backend nccl|gloo] [--c-abi-comm|--torch-comm] [--share-gpu]
+
+--backend nccl: one rank per GPU, RCCL (tests/test_hip_serving.py runs this when the box has two GPUs);
+--backend gloo --share-gpu: rehearsal on a one-GPU box, every rank on cuda:0.
+--c-abi-comm (levels only): the collective behind the C ABI (nst_comm_*: one ncclAllReduce of the packed gradient + loss
+row per closure); the communicator id travels over the torch.distributed process group."""
+import argparse
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
 import torch
+
 import bench
-from artstyletransfer_amd.engine import PixelOptimizer
-world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
-torch.cuda.set_device(0)
+from artstyletransfer_amd.engine import Communicator, PixelOptimizer
+
+ap = argparse.ArgumentParser()
+ap.add_argument("mode", choices=["levels", "stripes"])
+ap.add_argument("--backend", default="gloo")
+ap.add_argument("--c-abi-comm", action="store_true")
+ap.add_argument("--torch-comm", action="store_true")
+ap.add_argument("--share-gpu", action="store_true")
+ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--levels", type=int, default=3)
+args = ap.parse_args()
+
+world = int(os.environ.get("WORLD_SIZE", "1"))
+rank = int(os.environ.get("RANK", "0"))
+local = 0 if args.share_gpu or args.backend == "gloo" and torch.cuda.device_count() < world else int(os.environ.get("LOCAL_RANK", "0"))
+torch.cuda.set_device(local)
 dist = None
 if world > 1:
     import torch.distributed as dist
-    dist.init_process_group("gloo")
-mode = sys.argv[1] if len(sys.argv) > 1 else "levels"          # levels | stripes
-eng, x, cfg, host = bench.build_job(3, 0, 0)
-opt = PixelOptimizer(eng, "lbfgs", 10.0, 1)
-if world > 1 and mode == "levels":
-    opt.shard_levels(rank, world, dist)
-elif world > 1:
-    prep = lambda a: eng.prepare_img(torch.from_numpy(a).to(x.device))
-    opt.shard_stripes(rank, world, host[3], prep(host[0][0]), prep(host[1][0]), dist)
-out = []
-for k in range(5):
-    info, rows = opt.step(x, cfg.content_weight, cfg.style_weight, cfg.tv_weight)
-    out += [float(r[-1]) for r in rows] + [int(info.accepted)]
+    if args.backend == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        dist.init_process_group("gloo")
+
+
+def run(sharded):
+    eng, x, cfg, host = bench.build_job(args.levels, 0, local)
+    opt = PixelOptimizer(eng, "lbfgs", 10.0, 1)
+    comm = None
+    if sharded and args.mode == "levels" and args.c_abi_comm:
+        ids = [Communicator.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = Communicator(local, rank, world, ids[0])
+        opt.shard_levels_comm(comm)
+    elif sharded and args.mode == "levels":
+        opt.shard_levels(rank, world, dist)
+    elif sharded:
+        prep = lambda a: eng.prepare_img(torch.from_numpy(a).to(x.device))
+        opt.shard_stripes(rank, world, host[3], prep(host[0][0]), prep(host[1][0]), dist)
+    totals, accepted = [], []
+    for _ in range(args.steps):
+        info, rows = opt.step(x, cfg.content_weight, cfg.style_weight, cfg.tv_weight)
+        totals += [rows[k].copy() for k in range(len(rows))]
+        accepted.append(int(info.accepted))
+    out = (np.array(totals), accepted, float(x.double().sum()))
+    seen = comm.info() if comm is not None else None
+    opt.close()
+    if comm is not None:
+        comm.close()
+    eng.close()
+    return out, seen
+
+
+(sh_rows, sh_acc, sh_sum), seen = run(world > 1)
+(un_rows, un_acc, un_sum), _ = run(False)
 if rank == 0:
-    print("world", world, mode, "totals/accept:", out, "x checksum", float(x.double().sum()))
+    print("world", world, args.mode, "accepted", sh_acc, "x checksum", sh_sum, "comm (rank, world, calls, bytes)", seen)
+    assert sh_acc == un_acc, (sh_acc, un_acc)
+    acc_rows = [i for i in range(len(sh_rows))]
+    if args.mode == "levels":
+        # level rows have one contributor each and the total is re-formed in level order: bit-identical
+        assert np.array_equal(sh_rows, un_rows), np.abs(sh_rows - un_rows).max()
+        assert sh_sum == un_sum
+    else:
+        # stripes: gradients near a stripe boundary are sums of two separately rounded parts
+        np.testing.assert_allclose(sh_rows[:2], un_rows[:2], rtol=1e-5)
+        np.testing.assert_allclose(sh_rows[:, -1], un_rows[:, -1], rtol=1e-2)
+        assert abs(sh_sum - un_sum) <= 1e-9 * abs(un_sum)
+    print("SHARDED == UNSHARDED")
 if dist is not None:
-    dist.barrier(); dist.destroy_process_group()
+    dist.barrier()
+    dist.destroy_process_group()
