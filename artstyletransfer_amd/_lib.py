@@ -71,7 +71,9 @@ SYMBOLS = {
                                C.POINTER(StepInfo), c_void]),
     "nst_vgg_features": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.POINTER(c_void), c_void]),
     "nst_vgg_features_backward": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.POINTER(c_void), c_void, c_void]),
+    "nst_vgg_activations": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.POINTER(c_void), c_void]),
     "nst_level_activation": (C.c_int, [c_void, C.c_int, C.c_int, c_void, c_void]),
+    "nst_level_image": (C.c_int, [c_void, C.c_int, c_void, c_void]),
     "nst_gram": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void, c_void]),
     "nst_total_variation": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void, c_void]),
     "nst_bicubic_half": (C.c_int, [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void, c_void]),

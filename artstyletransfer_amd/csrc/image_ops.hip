@@ -17,19 +17,20 @@ static inline int img_blocks(size_t work) {
     return (int)b;
 }
 
-// ---- bicubic resize of an HWC image (cv2.INTER_CUBIC: A = -0.75, half-pixel centres, replicate border) ----
-__device__ __forceinline__ float icubic1(float x, float A) { return ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f; }
-__device__ __forceinline__ float icubic2(float x, float A) { return ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A; }
-__device__ __forceinline__ void itaps(int o, float scale, int n_in, int idx[4], float wt[4]) {
+// ---- bicubic resize of an HWC image: cv2.resize(..., INTER_CUBIC) for float images, in OpenCV's own arithmetic ----
+// source coordinate fx = (float)((dx + 0.5) * scale - 0.5) with scale in DOUBLE (resize.cpp forms it so and only then
+// drops to float), sx = floor(fx), t = fx - sx; weights = interpolateCubic(t) with A = -0.75 in float, the last one as
+// 1 - (w0 + w1 + w2); indices clamped (replicate border); no antialiasing when shrinking.
+__device__ __forceinline__ void itaps(int o, double scale, int n_in, int idx[4], float wt[4]) {
     const float A = -0.75f;
-    const float src = scale * (o + 0.5f) - 0.5f;
+    const float src = (float)(((double)o + 0.5) * scale - 0.5);
     const float fl = floorf(src);
     const float t = src - fl;
     const int i0 = (int)fl;
-    wt[0] = icubic2(t + 1.f, A);
-    wt[1] = icubic1(t, A);
-    wt[2] = icubic1(1.f - t, A);
-    wt[3] = icubic2(2.f - t, A);
+    wt[0] = ((A * (t + 1.f) - 5.f * A) * (t + 1.f) + 8.f * A) * (t + 1.f) - 4.f * A;
+    wt[1] = ((A + 2.f) * t - (A + 3.f)) * t * t + 1.f;
+    wt[2] = ((A + 2.f) * (1.f - t) - (A + 3.f)) * (1.f - t) * (1.f - t) + 1.f;
+    wt[3] = 1.f - wt[0] - wt[1] - wt[2];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         int j = i0 - 1 + k;
@@ -39,7 +40,7 @@ __device__ __forceinline__ void itaps(int o, float scale, int n_in, int idx[4], 
 
 __global__ void resize_hwc_kernel(const float* __restrict__ src, int h, int w, int C, float* __restrict__ dst, int oh,
                                   int ow) {
-    const float sh = (float)h / (float)oh, sw = (float)w / (float)ow;
+    const double sh = (double)h / (double)oh, sw = (double)w / (double)ow;
     const size_t total = (size_t)oh * ow * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);

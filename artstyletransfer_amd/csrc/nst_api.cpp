@@ -1369,6 +1369,24 @@ int nst_vgg_features(nst_ctx* ctx, const float* x, int h, int w, float* const* o
     return NST_OK;
 }
 
+int nst_vgg_activations(nst_ctx* ctx, const float* x, int h, int w, float* const* outs, void* stream) {
+    NSTCHK(bind(ctx));
+    if (!x || !outs) return fail(ctx, NST_E_ARG, "null argument");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    ActSet a;
+    int r = alloc_acts(ctx, a, h, w);
+    if (r == NST_OK) r = forward(ctx, a, x, h, w, s);
+    for (int l = 0; l < NL && r == NST_OK; ++l) {
+        if (!outs[l]) continue;
+        if (launch_hwc_to_chw(a.act[l], kCout[l], a.h[l], a.w[l], outs[l], s) != hipSuccess) r = fail(ctx, NST_E_HIP, "hwc_to_chw launch failed");
+    }
+    hipError_t e = hipStreamSynchronize(s);
+    free_acts(ctx, a);
+    if (r != NST_OK) return r;
+    HIPCHK(ctx, e);
+    return NST_OK;
+}
+
 int nst_level_activation(nst_ctx* ctx, int level, int layer, float* out, void* stream) {
     NSTCHK(bind(ctx));
     if (level < 0 || level >= ctx->levels) return fail(ctx, NST_E_STATE, "level not configured");
@@ -1376,6 +1394,17 @@ int nst_level_activation(nst_ctx* ctx, int level, int layer, float* out, void* s
     const ActSet& a = ctx->lv[level].acts;
     hipStream_t s = static_cast<hipStream_t>(stream);
     HIPCHK(ctx, launch_hwc_to_chw(a.act[layer], kCout[layer], a.h[layer], a.w[layer], out, s));
+    mark(ctx, s);
+    return NST_OK;
+}
+
+int nst_level_image(nst_ctx* ctx, int level, float* out, void* stream) {
+    NSTCHK(bind(ctx));
+    if (level < 1 || level >= ctx->levels) return fail(ctx, NST_E_ARG, "level must be 1 .. levels_num - 1 (level 0 is the caller's x)");
+    if (!out) return fail(ctx, NST_E_ARG, "null argument");
+    const LevelWs& L = ctx->lv[level];
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    HIPCHK(ctx, hipMemcpyAsync(out, L.xl, (size_t)3 * L.h * L.w * sizeof(float), hipMemcpyDeviceToDevice, s));
     mark(ctx, s);
     return NST_OK;
 }

@@ -245,6 +245,33 @@ class StyleEngine:
     LAYER_CHANNELS = (64, 64, 128, 128, 256, 256, 256, 256, 512, 512, 512, 512, 512)
     LAYER_SCALE = (0, 0, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4)
 
+    def vgg_activations(self, x: torch.Tensor) -> List[torch.Tensor]:
+        """All 13 post-ReLU conv outputs of a forward pass of x (nst_vgg_activations), each (1,C,h,w)."""
+        x = x.reshape(3, x.shape[-2], x.shape[-1])
+        _chk_dev(x, self.device)
+        h, w = x.shape[1], x.shape[2]
+        outs = [torch.empty((1, c, h >> sc, w >> sc), dtype=torch.float32, device=self.device)
+                for c, sc in zip(self.LAYER_CHANNELS, self.LAYER_SCALE)]
+        arr = (C.c_void_p * 13)(*[o.data_ptr() for o in outs])
+        _lib.check(self.ctx, self.lib.nst_vgg_activations(self.ctx, _ptr(x), h, w, arr, _stream(self.device)),
+                   "nst_vgg_activations")
+        return outs
+
+    def level_activation(self, level: int, layer: int) -> torch.Tensor:
+        h, w = self.level_shape(level)
+        c, sc = self.LAYER_CHANNELS[layer], self.LAYER_SCALE[layer]
+        t = torch.empty((1, c, h >> sc, w >> sc), dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_level_activation(self.ctx, level, layer, _ptr(t), _stream(self.device)),
+                   "nst_level_activation")
+        return t
+
+    def level_image(self, level: int) -> torch.Tensor:
+        """The (1,3,h,w) image of pyramid level `level` >= 1 that the last closure evaluated (nst_level_image)."""
+        h, w = self.level_shape(level)
+        t = torch.empty((1, 3, h, w), dtype=torch.float32, device=self.device)
+        _lib.check(self.ctx, self.lib.nst_level_image(self.ctx, level, _ptr(t), _stream(self.device)), "nst_level_image")
+        return t
+
     def level_activations(self, level: int) -> List[torch.Tensor]:
         """The 13 post-ReLU conv outputs the last closure left in the workspace of `level` (nst_level_activation),
         each (1,C,h,w): what the parity tests derive the device pass's ReLU / pooling decisions from."""

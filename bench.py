@@ -14,6 +14,13 @@ N > 1 (launched with torch.distributed.run, one rank per GPU): every rank optimi
 content x style job of the same shape (BASELINE config 5, task_executor throughput mode); there is
 no data-path collective, `value` is the whole-node closure rate, scaling is weak.
 
+Beside the headline (N = 1 only, after the timed region; none of it is inside `value`):
+  exact_f32        the same job on the exact fp32 MFMA (nst_options.conv_mode = f32), priced against the 157.3 TF fp32 peak;
+  sustained        the headline job kept running for >= 5 s whatever --steps says, with the shader clock sampled from sysfs;
+  progressing_job  jobs whose image moves at every step (Adam; L-BFGS with the 25-evaluation line search), so that the
+                   optimiser update with a filling curvature history is in a driver-seen number;
+  cpu_baseline     the oracle timed on this box's host cores on a bounded sample of the same job.
+
 Prints ONE JSON line (rank 0)."""
 from __future__ import annotations
 
@@ -35,7 +42,7 @@ import torch
 # so the matrix pipe executes 6x the algorithmic FLOPs and is priced against the bf16 peak.
 MFMA_PEAK = {"f32": 157.3, "bf16x3": 2500.0, "f16x2": 2500.0}
 MFMA_WORK_FACTOR = {"f32": 1.0, "bf16x3": 6.0, "f16x2": 3.0}
-MFMA_KERNEL = {"f32": "conv_mfma_kernel", "bf16x3": "conv_bf3_kernel", "f16x2": "conv_h2_kernel"}
+MFMA_KERNEL = {"f32": "conv_mfma_kernel", "bf16x3": "conv_bf3_batch_kernel", "f16x2": "conv_h2_batch_kernel"}
 MFMA_DTYPE = {"f32": "f32",
               "bf16x3": "bf16 (3 exact pieces per fp32 operand, 6 MFMAs per product, fp32 accumulate)",
               "f16x2": "f16 (2 scaled pieces per fp32 operand = 22 significand bits, 3 MFMAs per product, main and "
@@ -44,22 +51,90 @@ DTYPE = {"f32": "f32", "bf16x3": "f32 via bf16x3 split (6 bf16 MFMAs per product
          "f16x2": "f32 via f16x2 split (3 f16 MFMAs per product, f32 accumulate)"}
 
 
-def pmc_traffic_per_launch(kernel_prefix):
-    """HBM GB per launch of the dominant kernel from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json,
-    written by tools/summarize_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the same L=2
-    closure; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  None when the file is absent or
-    the workload is not the L=2 one it was collected on."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")
-    try:
-        kernels = json.load(open(path))["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    n = b = 0
-    for name, e in kernels.items():
-        if name.startswith(kernel_prefix):
-            n += e["launches"]
-            b += e["fetch_bytes_corrected"] + e["write_bytes"]
-    return (b / n / 1e9) if n else None
+TRAFFIC_PROFILES = ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")
+
+
+def committed_traffic_per_launch(kernel_prefix):
+    """HBM GB per launch of the dominant kernel from the COMMITTED PMC passes (profiles/r0N_pmc_hbm_traffic.json, written
+    by tools/summarize_pmc.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of the same L=2 closure;
+    FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  It is a replayed figure, not a measurement of this
+    run (hardware counters need rocprofv3 around the process), and is reported under that name; roofline.traffic stays
+    null.  None when no file is there."""
+    for name in TRAFFIC_PROFILES:
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            kernels = json.load(open(path))["kernels"]
+        except (OSError, ValueError, KeyError):
+            continue
+        n = b = 0
+        for kname, e in kernels.items():
+            if kname.startswith(kernel_prefix):
+                n += e["launches"]
+                b += e["fetch_bytes_corrected"] + e["write_bytes"]
+        if n:
+            return {"gb_per_launch": b / n / 1e9, "file": f"profiles/{name}",
+                    "what": "HBM GB per launch of the dominant kernel, rocprofv3 PMC passes of an earlier run of this workload"}
+    return None
+
+
+class GpuSampler:
+    """Shader clock (and board power) of one GPU sampled from sysfs every 50 ms on a thread: what the sustained figure is
+    quoted with.  The conv kernel is power/clock bound, so a rate is only meaningful with its clock."""
+
+    def __init__(self, device_index: int):
+        import glob
+        import threading
+        self.paths = {}
+        try:
+            props = torch.cuda.get_device_properties(device_index)
+            bdf = f"{getattr(props, 'pci_domain_id', 0):04x}:{props.pci_bus_id:02x}:{props.pci_device_id:02x}.0"
+            base = f"/sys/bus/pci/devices/{bdf}"
+            for key, pat in (("sclk_hz", "hwmon/hwmon*/freq1_input"), ("power_uw", "hwmon/hwmon*/power1_average"),
+                             ("power_uw_in", "hwmon/hwmon*/power1_input")):
+                hits = glob.glob(os.path.join(base, pat))
+                if hits:
+                    self.paths[key] = hits[0]
+            self.dpm = os.path.join(base, "pp_dpm_sclk") if os.path.exists(os.path.join(base, "pp_dpm_sclk")) else None
+        except Exception:
+            self.dpm = None
+        self.samples = {"sclk_mhz": [], "power_w": []}
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _read(self):
+        try:
+            if "sclk_hz" in self.paths:
+                self.samples["sclk_mhz"].append(int(open(self.paths["sclk_hz"]).read()) / 1e6)
+            elif self.dpm:
+                for line in open(self.dpm):
+                    if "*" in line:
+                        self.samples["sclk_mhz"].append(float(line.split(":")[1].lower().replace("mhz", "").replace("*", "").strip()))
+            for k in ("power_uw", "power_uw_in"):
+                if k in self.paths:
+                    self.samples["power_w"].append(int(open(self.paths[k]).read()) / 1e6)
+                    break
+        except Exception:
+            pass
+
+    def _run(self):
+        while not self._stop.is_set():
+            self._read()
+            self._stop.wait(0.05)
+
+    def __enter__(self):
+        self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        self._thread.join()
+
+    def summary(self):
+        out = {}
+        for k, v in self.samples.items():
+            if v:
+                out[k] = {"min": round(min(v), 1), "mean": round(sum(v) / len(v), 1), "max": round(max(v), 1), "samples": len(v)}
+        return out or None
 
 
 def mfma_roofline(mode, algorithmic_flops, ms, launches, extra=None):
@@ -70,7 +145,8 @@ def mfma_roofline(mode, algorithmic_flops, ms, launches, extra=None):
            "mfma_dtype": MFMA_DTYPE[mode],
            "achieved": hw, "peak": MFMA_PEAK[mode], "unit": "TFLOP/s", "frac": hw / MFMA_PEAK[mode],
            "algorithmic_tflops": alg, "mfma_work_factor": MFMA_WORK_FACTOR[mode],
-           "frac_algorithmic_of_fp32_mfma_peak": alg / MFMA_PEAK["f32"],
+           # NOT a roofline fraction: how many times the fp32-MFMA peak RATE (157.3 TF) the algorithmic rate is
+           "algorithmic_rate_over_fp32_mfma_peak_rate": alg / MFMA_PEAK["f32"],
            # tools/micro/mfma_power.hip on this pool, random fp16 operands: MFMA-only kernel 1 680 TFLOP/s (zeros: 2 460),
            # with the conv kernel's LDS fragment traffic 1 560
            "frac_of_measured_random_data_mfma_ceiling": (hw / 1680.0) if mode != "f32" else None,
@@ -141,13 +217,11 @@ def cpu_baseline(job_host, cfg, closures: int):
             "seconds": round(total, 2)}
 
 
-def one_stream_pass(args, cfg, closures: int = 6):
-    """Per-kernel durations with every level serialised on one stream (a second engine on the same workload)."""
-    os.environ["NST_SINGLE_STREAM"] = "1"
-    try:
-        eng, x, _, _ = build_job(args.levels, 0, torch.cuda.current_device())
-    finally:
-        del os.environ["NST_SINGLE_STREAM"]
+def one_stream_pass(args, cfg, closures: int = 6, **engine_options):
+    """Per-kernel durations with every level serialised on one stream (a second engine on the same workload): under the
+    per-level schedule the levels run on streams of their own, and a launch's duration is not its own while kernels of
+    other levels share the CUs."""
+    eng, x, _, _ = build_job(args.levels, 0, torch.cuda.current_device(), batched=False, single_stream=True, **engine_options)
     cw, sw, tvw = cfg.content_weight, cfg.style_weight, cfg.tv_weight
     for _ in range(2):
         eng.closure(x, cw, sw, tvw)
@@ -165,6 +239,89 @@ def one_stream_pass(args, cfg, closures: int = 6):
     return res
 
 
+class JobLoop:
+    """One job's optimiser loop with the per-step image yield as NeuralStyleTransfer.process does it: un-prepare on the
+    device, D2H into pinned memory on a side stream, so the copy of step k runs under the closures of step k+1; it is
+    awaited before the next yield (two host buffers)."""
+
+    def __init__(self, eng, x, opt, weights3, do_yield=True, stream=None):
+        self.eng, self.x, self.opt, self.stream = eng, x, opt, stream
+        self.cw, self.sw, self.tvw = weights3
+        self.do_yield = do_yield
+        H, W = eng.shape
+        self.img_host = [torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream()
+        self.copy_done = [None, None]
+        self.result = (0, None)
+        self.opt_steps = 0
+        self.accepted = 0
+        self.history = 0
+
+    def run(self, closures: int):
+        if self.stream is not None:                      # an extra job: its own stream (per-thread current stream)
+            with torch.cuda.stream(self.stream):
+                self.result = self._run(closures)
+        else:
+            self.result = self._run(closures)
+        return self.result
+
+    def _run(self, closures: int):
+        done = 0
+        last = None
+        k = 0
+        while done < closures:
+            info, rows = self.opt.step(self.x, self.cw, self.sw, self.tvw, want_losses=True)
+            done += info.closures
+            self.opt_steps += 1
+            self.accepted += int(info.accepted)
+            self.history = int(info.history)
+            last = rows
+            if self.do_yield:
+                snap = self.eng.unprepare_img(self.x)
+                ready = torch.cuda.Event()
+                ready.record()
+                if self.copy_done[k] is not None:
+                    self.copy_done[k].synchronize()           # the consumer is done with this host buffer
+                with torch.cuda.stream(self.copy_stream):
+                    self.copy_stream.wait_event(ready)
+                    self.img_host[k].copy_(snap, non_blocking=True)
+                    snap.record_stream(self.copy_stream)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                self.copy_done[k] = ev
+                k ^= 1
+        for ev in self.copy_done:
+            if ev is not None:
+                ev.synchronize()
+        return done, last
+
+
+def timed(job: JobLoop, closures: int):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    done, rows = job.run(closures)
+    torch.cuda.synchronize()
+    return done, time.perf_counter() - t0, rows
+
+
+def side_job(args, optimizer, max_eval, closures, warm, **engine_options):
+    """A fresh engine on the same workload with another optimiser / arithmetic, timed like the headline (per-step yield
+    included).  Returns (dict, engine still open for its timing totals)."""
+    from artstyletransfer_amd.engine import PixelOptimizer
+    eng, x, cfg, _ = build_job(args.levels, 0, torch.cuda.current_device(), **engine_options)
+    opt = PixelOptimizer(eng, optimizer, 10.0, max_eval)
+    job = JobLoop(eng, x, opt, (cfg.content_weight, cfg.style_weight, cfg.tv_weight), not args.no_yield)
+    eng.closure(x, cfg.content_weight, cfg.style_weight, cfg.tv_weight)      # cold launches outside the timed region
+    job.run(warm)
+    first = None
+    done, dt, rows = timed(job, closures)
+    out = {"value": done / dt, "unit": "iters/s", "ms_per_step": dt / done * 1e3, "steps": done,
+           "optimizer": optimizer if optimizer == "adam" else f"lbfgs, max_eval {max_eval}",
+           "optimizer_steps": job.opt_steps, "accepted_steps": job.accepted, "history_pairs": job.history,
+           "final_loss": float(rows[-1][-1]) if rows is not None else None}
+    return out, eng, opt, job
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,12 +329,20 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--levels", type=int, default=3, help="levels_num (3 = BASELINE L=2)")
     ap.add_argument("--optimizer", default="lbfgs", choices=["lbfgs", "adam"])
+    ap.add_argument("--lbfgs-max-eval", type=int, default=1,
+                    help="1 = the reference's constructor arguments under torch 2.10 (one trial point per step, almost always "
+                         "rejected: SURVEY F5); 26 = the line search older torch performed")
     ap.add_argument("--no-yield", action="store_true", help="skip the per-step image yield (unprepare + D2H)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip exact_f32 / sustained / progressing_job")
+    ap.add_argument("--sustained-seconds", type=float, default=5.0)
     ap.add_argument("--cpu-closures", type=int, default=2)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--time-all-kernels", action="store_true", help="event pairs around every launch (slower)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (rehearsals)")
+    ap.add_argument("--comm", default="c-abi", choices=["c-abi", "torch"],
+                    help="mode 'levels': the per-closure collective behind the C ABI (nst_comm_*: one ncclAllReduce of the "
+                         "packed gradient + loss row) or through torch.distributed (needed for gloo rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
     ap.add_argument("--jobs-per-gpu", type=int, default=1,
                     help="mode 'jobs' only: that many independent jobs per GPU, each on its own HIP stream and host "
@@ -207,69 +372,30 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
-    from artstyletransfer_amd.engine import PixelOptimizer
+    from artstyletransfer_amd.engine import Communicator, PixelOptimizer
     sharded = world > 1 and args.mode in ("levels", "stripes")
     eng, x, cfg, job_host = build_job(args.levels, 0 if sharded else rank, local_rank)
     cfg.optimizer = args.optimizer
-    opt = PixelOptimizer(eng, args.optimizer, 10.0, 1)
+    opt = PixelOptimizer(eng, args.optimizer, 10.0, args.lbfgs_max_eval)
+    comm = None
     if sharded and args.mode == "levels":
-        opt.shard_levels(rank, world, dist)
+        if args.comm == "c-abi" and args.dist_backend == "nccl" and not args.share_gpu:
+            ids = [Communicator.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = Communicator(local_rank, rank, world, ids[0])
+            opt.shard_levels_comm(comm)
+        else:
+            opt.shard_levels(rank, world, dist)
     elif sharded:
         # the top level cut into horizontal stripes (+ halo), the lower levels dealt out by level
         prep = lambda a: eng.prepare_img(torch.from_numpy(a).to(x.device))
         opt.shard_stripes(rank, world, job_host[3], prep(job_host[0][0]), prep(job_host[1][0]), dist)
-    cw, sw, tvw = cfg.content_weight, cfg.style_weight, cfg.tv_weight
+    w3 = (cfg.content_weight, cfg.style_weight, cfg.tv_weight)
+    cw, sw, tvw = w3
     H, W = eng.shape
-    per_step = 2 if args.optimizer == "lbfgs" else 1
+    per_step = 2 if (args.optimizer == "lbfgs" and args.lbfgs_max_eval == 1) else 1
 
-    class JobLoop:
-        """One job's optimiser loop with the per-step image yield as NeuralStyleTransfer.process does it: un-prepare on
-        the device, D2H into pinned memory on a side stream, so the copy of step k runs under the closures of step
-        k+1; it is awaited before the next yield (two host buffers)."""
-
-        def __init__(self, eng, x, opt, stream=None):
-            self.eng, self.x, self.opt, self.stream = eng, x, opt, stream
-            self.img_host = [torch.empty((H, W, 3), dtype=torch.float32, pin_memory=True) for _ in range(2)]
-            self.copy_stream = torch.cuda.Stream()
-            self.copy_done = [None, None]
-            self.result = (0, None)
-
-        def run(self, closures: int):
-            if self.stream is not None:                      # an extra job: its own stream (per-thread current stream)
-                with torch.cuda.stream(self.stream):
-                    self.result = self._run(closures)
-            else:
-                self.result = self._run(closures)
-            return self.result
-
-        def _run(self, closures: int):
-            done = 0
-            last = None
-            k = 0
-            while done < closures:
-                info, rows = self.opt.step(self.x, cw, sw, tvw, want_losses=True)
-                done += info.closures
-                last = rows
-                if not args.no_yield:
-                    snap = self.eng.unprepare_img(self.x)
-                    ready = torch.cuda.Event()
-                    ready.record()
-                    if self.copy_done[k] is not None:
-                        self.copy_done[k].synchronize()           # the consumer is done with this host buffer
-                    with torch.cuda.stream(self.copy_stream):
-                        self.copy_stream.wait_event(ready)
-                        self.img_host[k].copy_(snap, non_blocking=True)
-                        snap.record_stream(self.copy_stream)
-                        ev = torch.cuda.Event()
-                        ev.record()
-                    self.copy_done[k] = ev
-                    k ^= 1
-            for ev in self.copy_done:
-                if ev is not None:
-                    ev.synchronize()
-            return done, last
-
-    jobs = [JobLoop(eng, x, opt)]
+    jobs = [JobLoop(eng, x, opt, w3, not args.no_yield)]
     extra = []
     if args.jobs_per_gpu > 1:
         if sharded:
@@ -278,9 +404,9 @@ def main():
             st = torch.cuda.Stream()
             with torch.cuda.stream(st):
                 e2, x2, _, _ = build_job(args.levels, world * j + rank, local_rank)
-                o2 = PixelOptimizer(e2, args.optimizer, 10.0, 1)
+                o2 = PixelOptimizer(e2, args.optimizer, 10.0, args.lbfgs_max_eval)
             extra.append((e2, o2))
-            jobs.append(JobLoop(e2, x2, o2, st))
+            jobs.append(JobLoop(e2, x2, o2, w3, not args.no_yield, st))
         torch.cuda.synchronize()
 
     def run(closures: int):
@@ -314,6 +440,8 @@ def main():
         # a pair around each of them in every closure costs 5 % of the closure rate, around all ~50 launches 8 %
         eng.set_timing(4 if not args.time_all_kernels else 2)
         eng.timing_totals(0, reset=True)
+    for j in jobs:
+        j.opt_steps = j.accepted = 0
     barrier()
     t0 = time.perf_counter()
     done, last_rows = run(steps)
@@ -327,6 +455,9 @@ def main():
     if rank == 0:
         px = sum((H >> l) * (W >> l) for l in range(args.levels))
         closure_flops = 1514240.0 * px                        # conv fwd+dgrad + Gram fwd+bwd
+        opt_name = args.optimizer if args.optimizer == "adam" else (
+            "lbfgs as the reference constructs it (max_eval 1 under torch 2.10)" if args.lbfgs_max_eval == 1
+            else f"lbfgs with max_eval {args.lbfgs_max_eval}")
         out = {
             "metric": "style-transfer iters/sec at L=2 (1024-px)" if args.levels == 3 else f"style-transfer iters/sec at L={args.levels - 1}",
             "value": total_done / dt,
@@ -342,24 +473,30 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"pyramid style transfer, levels_num={args.levels} "
                                    f"({'+'.join(f'{W >> l}x{H >> l}' for l in range(args.levels))}), "
-                                   f"{args.optimizer} as the reference constructs it, content+noise init, "
+                                   f"{opt_name}, content+noise init, "
                                    f"seeded synthetic VGG19 weights, per-step image yield "
                                    f"{'off' if args.no_yield else 'on'}",
                        "iter": "one closure evaluation (forward + losses + backward of every level) + its share of the optimiser update",
                        "parallelism": (("1 GPU" if args.jobs_per_gpu == 1 else f"1 GPU, {args.jobs_per_gpu} jobs on their own streams") if world == 1 else
-                                       (f"levels sharded over {world} ranks, RCCL all-reduce of the pixel gradient"
+                                       (f"levels sharded over {world} ranks, one RCCL all-reduce of the packed pixel gradient + loss row per closure"
+                                        + (" behind the C ABI (nst_comm)" if comm is not None else " through torch.distributed")
                                         if args.mode == "levels" else
                                         f"top level in {world} stripes (+96-row halo), lower levels by level; all-reduce of the "
                                         f"Gram/content/TV sums and of the pixel gradient per closure")
                                        if sharded else (f"{args.jobs_per_gpu} job(s) per GPU on their own streams, no collective" if args.jobs_per_gpu > 1 else "1 job per GPU, no collective")),
                        "final_loss": float(last_rows[-1][-1]) if last_rows is not None else None,
                        "job_setup_ms_on_device": round(getattr(cfg, "job_setup_ms", 0.0), 1)},
+            # what the optimiser did in the timed region: with the reference's L-BFGS arguments under torch 2.10 almost
+            # every trial step is rejected, so the curvature history stays (nearly) empty - see progressing_job
+            "optimizer_steps": jobs[0].opt_steps, "accepted_steps": jobs[0].accepted, "lbfgs_history_pairs": jobs[0].history,
             "closure_tflops_algorithmic": closure_flops / 1e12,
             "closure_rate_tflops": closure_flops * (done / dt) / 1e12,
-            # whole-closure algorithmic rate over the fp32 matrix peak (the arithmetic the reference's
-            # torch path would need on this chip); > 1 because the products run as fp16 pieces on the 16-bit pipe
-            "closure_frac_of_fp32_mfma_peak": closure_flops * (done / dt) / 1e12 / MFMA_PEAK["f32"],
         }
+        if comm is not None:
+            r_, w_, calls, nbytes = comm.info()
+            out["comm"] = {"ranks_seen": w_, "allreduce_calls": calls, "bytes_per_call": nbytes / max(calls, 1)}
+        elif dist is not None:
+            out["comm"] = {"ranks_seen": dist.get_world_size(), "backend": args.dist_backend}
         if not args.no_kernel_timing:
             ms, n, fl = eng.timing_totals(0)
             cms, cn, _ = eng.timing_totals(-1)
@@ -368,24 +505,47 @@ def main():
             c1ms, c1n, c1fl = eng.timing_totals(2)
             out["roofline"] = mfma_roofline(eng.conv_mode(), fl, ms, n)
             if args.levels == 3 and eng.conv_mode() == "f16x2" and not sharded:
-                gb = pmc_traffic_per_launch("conv_h2")
-                if gb is not None:
-                    out["roofline"]["traffic"] = gb
-                    out["roofline"]["traffic_unit"] = "GB of HBM per launch (rocprofv3 PMC passes, profiles/r01_pmc_hbm_traffic.json)"
+                out["roofline"]["traffic_from_committed_profile"] = committed_traffic_per_launch("conv_h2")
             _, sampled, _ = eng.timing_totals(-2)
             out["roofline"]["sampled_closures"] = sampled
             out["kernel_ms_per_closure"] = {"closure": cms / max(cn, 1), "conv3x3_mfma": ms / max(sampled, 1)}
             if args.time_all_kernels:
                 out["kernel_ms_per_closure"].update({"gram_mfma": gms / max(cn, 1), "conv1_1": c1ms / max(cn, 1),
                                                      "streaming": oms / max(cn, 1)})
-            if world == 1 and os.environ.get("NST_BATCH") == "0" and not os.environ.get("NST_SINGLE_STREAM"):
-                # Under the NST_BATCH=0 schedule the pyramid levels run on separate HIP streams, so the launch durations
-                # above are taken while kernels of other levels share the CUs (their sum exceeds the closure time).
-                # The same closures re-run on ONE stream give each kernel's duration with the chip to itself.
-                out["roofline"]["note"] = ("launch durations measured while kernels of the other pyramid levels run "
-                                           "concurrently on their own streams; roofline_one_stream = same closures "
-                                           "serialised on one stream")
-                out["roofline_one_stream"] = one_stream_pass(args, cfg)
+        extras = world == 1 and args.jobs_per_gpu == 1 and not args.no_extras
+        if extras:
+            # ---- sustained: the same job goes on for >= 5 s, whatever --steps was; clock sampled from sysfs
+            eng.set_timing(0)
+            chunk = 20 * per_step
+            sdone, st0 = 0, time.perf_counter()
+            with GpuSampler(local_rank) as smp:
+                while time.perf_counter() - st0 < args.sustained_seconds:
+                    d, _ = jobs[0].run(chunk)
+                    sdone += d
+                torch.cuda.synchronize()
+                sdt = time.perf_counter() - st0
+            out["sustained"] = {"seconds": round(sdt, 2), "steps": sdone, "value": sdone / sdt, "unit": "iters/s",
+                                "ms_per_step": sdt / sdone * 1e3, "gpu": smp.summary()}
+            # ---- the exact fp32 MFMA on the same job
+            f32, e32, o32, _ = side_job(args, args.optimizer, args.lbfgs_max_eval, 4 * per_step, per_step, conv_mode="f32")
+            o32.close()
+            e32.close()
+            f32["dtype"] = DTYPE["f32"]
+            f32["schedule"] = "one launch per layer and level, levels on HIP streams of their own (the f32 kernel has no batched form)"
+            f32["roofline"] = one_stream_pass(args, cfg, 3, conv_mode="f32")
+            f32["roofline"]["note"] = "launch durations from the same closures serialised on ONE stream (each kernel with the chip to itself)"
+            out["exact_f32"] = f32
+            # ---- jobs that make progress
+            prog = {}
+            a, ea, oa, _ = side_job(args, "adam", 1, 40, 4)
+            prog["adam"] = a
+            oa.close()
+            ea.close()
+            ls, el, ol, _ = side_job(args, "lbfgs", 26, 60, 10)
+            prog["lbfgs_line_search"] = ls
+            ol.close()
+            el.close()
+            out["progressing_job"] = prog
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(job_host, cfg, args.cpu_closures)
         print(json.dumps(out), flush=True)
@@ -393,6 +553,8 @@ def main():
         o2.close()
         e2.close()
     opt.close()
+    if comm is not None:
+        comm.close()
     eng.close()
     if dist is not None:
         dist.barrier()

@@ -8,11 +8,17 @@
  *       -Lartstyletransfer_amd -lnst_hip -L/opt/rocm/lib -lamdhip64 -lm \
  *       -Wl,-rpath,$PWD/artstyletransfer_amd -Wl,-rpath,/opt/rocm/lib -o /tmp/nst_min
  *   /tmp/nst_min [adam|lbfgs] [steps]
+ *
+ * Level sharding over several GPUs without Python (BASELINE config 4): start one process per GPU,
+ *   /tmp/nst_min lbfgs 6 <rank> <world> <id-file>
+ * Rank 0 writes the communicator id (nst_comm_unique_id) to <id-file>, the others read it; every rank then evaluates the
+ * pyramid levels l % world == rank and the driver all-reduces the packed gradient + loss row over RCCL per closure.
  */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include <hip/hip_runtime_api.h>
 
@@ -65,12 +71,39 @@ static float* prepared_image(nst_ctx* ctx, int h, int w, float phase) {
     return dev;
 }
 
+/* the NST_COMM_ID_BYTES of rank 0's nst_comm_unique_id, handed over through a file (any channel would do) */
+static int exchange_id(const char* path, int rank, unsigned char* id) {
+    if (rank == 0) {
+        char tmp[1024];
+        FILE* f;
+        if (nst_comm_unique_id(id) != NST_OK) return 1;
+        snprintf(tmp, sizeof tmp, "%s.tmp", path);
+        f = fopen(tmp, "wb");
+        if (!f || fwrite(id, 1, NST_COMM_ID_BYTES, f) != NST_COMM_ID_BYTES) return 1;
+        fclose(f);
+        return rename(tmp, path) != 0;            /* atomic: readers never see a partial file */
+    }
+    for (int tries = 0; tries < 6000; ++tries) {
+        FILE* f = fopen(path, "rb");
+        if (f) {
+            size_t n = fread(id, 1, NST_COMM_ID_BYTES, f);
+            fclose(f);
+            if (n == NST_COMM_ID_BYTES) return 0;
+        }
+        struct timespec ts = {0, 10 * 1000 * 1000};
+        nanosleep(&ts, NULL);
+    }
+    return 1;
+}
+
 int main(int argc, char** argv) {
     const int kind = (argc > 1 && strcmp(argv[1], "adam") == 0) ? NST_OPT_ADAM : NST_OPT_LBFGS;
     const int steps = argc > 2 ? atoi(argv[2]) : 6;
+    const int rank = argc > 5 ? atoi(argv[3]) : 0, world = argc > 5 ? atoi(argv[4]) : 1;
     const int H = 96, W = 144, levels = 2;
     nst_ctx* ctx = NULL;
     nst_opt* opt = NULL;
+    nst_comm* comm = NULL;
     int ndev = 0;
 
     if (nst_device_count(&ndev) != NST_OK || ndev < 1) { fprintf(stderr, "no GPU: the engine has no CPU path\n"); return 2; }
@@ -85,7 +118,11 @@ int main(int argc, char** argv) {
         b[l] = (float*)calloc((size_t)kCout[l], sizeof(float));
         for (size_t i = 0; i < nw; ++i) w[l][i] = sd * gaussian();
     }
-    CHECK_NST(nst_ctx_create(0, (const float* const*)w, (const float* const*)b, &ctx));
+    /* options as arguments (fields left at -1 fall back to the environment, then to the defaults) */
+    nst_options opts;
+    nst_options_default(&opts);
+    opts.conv_mode = NST_CONV_F16X2;
+    CHECK_NST(nst_ctx_create_ex(world > 1 ? rank % ndev : 0, (const float* const*)w, (const float* const*)b, &opts, &ctx));
     for (int l = 0; l < NST_VGG19_CONVS; ++l) { free(w[l]); free(b[l]); }
 
     CHECK_NST(nst_job_configure(ctx, levels, H, W));
@@ -103,6 +140,14 @@ int main(int argc, char** argv) {
     if (!x) { fprintf(stderr, "device allocation failed\n"); return 1; }
 
     CHECK_NST(nst_opt_create(ctx, kind, kind == NST_OPT_ADAM ? 10.0f : 1.0f, 26, &opt));
+    if (world > 1) {
+        unsigned char id[NST_COMM_ID_BYTES];
+        unsigned mask = 0;
+        if (exchange_id(argv[5], rank, id)) { fprintf(stderr, "communicator id exchange failed: %s\n", nst_last_error(NULL)); return 1; }
+        CHECK_NST(nst_comm_create(rank % ndev, rank, world, id, &comm));
+        for (int l = 0; l < levels; ++l) if (l % world == rank) mask |= 1u << l;
+        CHECK_NST(nst_opt_shard_levels_comm(opt, mask, comm));
+    }
     float first = 0.f, last = 0.f;
     for (int s = 0; s < steps; ++s) {
         nst_step_info info;
@@ -117,6 +162,7 @@ int main(int argc, char** argv) {
     }
     printf("first %.6e last %.6e %s\n", first, last, last < first ? "DECREASED" : "NOT-DECREASED");
     nst_opt_destroy(opt);
+    nst_comm_destroy(comm);
     nst_ctx_destroy(ctx);
     CHECK_HIP(hipFree(x));
     return last < first ? 0 : 3;

@@ -180,6 +180,9 @@ int nst_lbfgs_direction(nst_ctx* ctx, const float* g, const float* const* y, con
 /* Vgg19.forward (neural_nets.py:53-68): x device (3,h,w) -> the six maps, each written as
  * (C,h_i,w_i) planar fp32 (reference layout) into outs[i] (device; NULL to skip). */
 int nst_vgg_features(nst_ctx* ctx, const float* x, int h, int w, float* const* outs, void* stream);
+/* The same forward pass, all 13 post-ReLU conv outputs conv1_1 ... conv5_1 as (C,h_l,w_l) planar fp32 into outs[l]
+ * (device; NULL to skip): the decisions (unit on / pooling arg-max) nst_vgg_features_backward of the same x takes. */
+int nst_vgg_activations(nst_ctx* ctx, const float* x, int h, int w, float* const* outs, void* stream);
 /* d(sum_i <outs_i, gouts_i>)/dx through the network: gouts[i] device (C,h_i,w_i) or NULL. */
 int nst_vgg_features_backward(nst_ctx* ctx, const float* x, int h, int w, const float* const* gouts,
                               float* gx, void* stream);
@@ -188,6 +191,11 @@ int nst_vgg_features_backward(nst_ctx* ctx, const float* x, int h, int w, const 
  * ReLU and max-pool DECISIONS of the device pass from it (a unit is on where the value is > 0; a pooling window passes its
  * gradient to its first maximum) and hand them to the oracle, so that gradients are compared under equal decisions. */
 int nst_level_activation(nst_ctx* ctx, int level, int layer, float* out, void* stream);
+/* The image of pyramid level `level` >= 1 that the last closure evaluated - the bicubic 1/2 chain of x
+ * (neural_style_transfer.py:170-176) - as (3,h_l,w_l) planar fp32 to out (device).  The total-variation term takes
+ * sign(y_i - y_j) of neighbouring pixels: on flat image regions those differences are rounding noise of the down-sampling,
+ * so the parity tests read the signs the device pass took from this image. */
+int nst_level_image(nst_ctx* ctx, int level, float* out, void* stream);
 /* math_utils.gram_matrix (math_utils.py:26-34): f device (C,h,w) -> gram device (C,C). */
 int nst_gram(nst_ctx* ctx, const float* f, int C, int h, int w, int normalize, float* gram, void* stream);
 /* math_utils.total_variation (math_utils.py:37-41): value (device scalar) and, if grad != NULL,

@@ -106,9 +106,16 @@ def gram_matrix(x: torch.Tensor, should_normalize: bool = True) -> torch.Tensor:
     return g
 
 
-def total_variation(y: torch.Tensor) -> torch.Tensor:
-    mx = torch.mean(torch.abs(y[:, :, :, :-1] - y[:, :, :, 1:]))
-    my = torch.mean(torch.abs(y[:, :, :-1, :] - y[:, :, 1:, :]))
+def total_variation(y: torch.Tensor, signs=None) -> torch.Tensor:
+    """math_utils.py:37-41.  `signs` = (sx, sy): evaluate |d| as s * d with the signs ANOTHER evaluation took (see
+    Decisions.tv): on flat image regions the neighbour differences of a down-sampled level are rounding noise whose
+    sign is arbitrary, and abs' sub-gradient sign(d) turns that into a gradient difference of order one."""
+    dx = y[:, :, :, :-1] - y[:, :, :, 1:]
+    dy = y[:, :, :-1, :] - y[:, :, 1:, :]
+    if signs is None:
+        mx, my = torch.mean(torch.abs(dx)), torch.mean(torch.abs(dy))
+    else:
+        mx, my = torch.mean(signs[0] * dx), torch.mean(signs[1] * dy)
     return mx * mx + my * my
 
 
@@ -123,8 +130,13 @@ class Decisions:
     within rounding of 0 otherwise lands on different sides and changes the gradient over that unit's whole receptive
     field.  (The tests also check that the two evaluations' own decisions differ only at such near-ties.)"""
 
-    def __init__(self, activations: Sequence[torch.Tensor]):
+    def __init__(self, activations: Sequence[torch.Tensor], level_image: Optional[torch.Tensor] = None):
         assert len(activations) == len(VGG19_CONVS)
+        # the signs the other pass's total-variation term took (None: this evaluation's own)
+        self.tv = None
+        if level_image is not None:
+            y = level_image
+            self.tv = (torch.sign(y[:, :, :, :-1] - y[:, :, :, 1:]), torch.sign(y[:, :, :-1, :] - y[:, :, 1:, :]))
         self.relu = [a > 0 for a in activations]
         self.pool = {}
         for (name, _, _), a in zip(VGG19_CONVS, activations):
@@ -197,7 +209,7 @@ def level_loss(x: torch.Tensor, tg: LevelTargets, weights, cw: float, sw: float,
     for g_gt, i in zip(tg.grams, STYLE_INDICES):
         style = style + F.mse_loss(g_gt[0], gram_matrix(feats[i])[0], reduction="mean")
     style = style / len(tg.grams)
-    tv = total_variation(x)
+    tv = total_variation(x, decisions.tv if decisions is not None else None)
     total = cw * content + sw * style + tvw * tv
     return total, content, style, tv
 

@@ -19,7 +19,7 @@ def _build(tmp_path):
         import __graft_entry__ as g
         g.build()
     exe = str(tmp_path / "nst_min")
-    cmd = ["gcc", "-std=c99", "-O2", "-Wall", "-Werror", f"-I{ROOT}/include", f"-I{ROCM}/include", "-D__HIP_PLATFORM_AMD__", SRC,
+    cmd = ["gcc", "-std=gnu99", "-O2", "-Wall", "-Werror", f"-I{ROOT}/include", f"-I{ROCM}/include", "-D__HIP_PLATFORM_AMD__", SRC,
            f"-L{LIBDIR}", "-lnst_hip", f"-L{ROCM}/lib", "-lamdhip64", "-lm", f"-Wl,-rpath,{LIBDIR}", f"-Wl,-rpath,{ROCM}/lib",
            "-o", exe]
     subprocess.run(cmd, check=True, capture_output=True, text=True)

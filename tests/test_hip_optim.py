@@ -259,10 +259,10 @@ def test_config2_geometry_lbfgs_line_search_vs_reference(eng, vgg_weights, golde
     report(f"config-2 geometry (lbfgs max_eval 26, 100 closures): {len(steps)} steps (reference {len(fx['steps'])}), history pairs "
            f"{hist[0]}; accepted-point loss rel err per step {np.array2string(rel, precision=1)}; last {my_f[-1]:.5e} vs {ref_f[-1]:.5e}")
     assert all(moved) and hist[0] >= len(steps) - 2
-    assert rel[0] < 1e-5
-    assert my_f[-1] < 0.5 * my_f[0] and ref_f[-1] < 0.5 * ref_f[0]   # both jobs make progress ...
-    lo, hi = sorted((float(my_f[-1]), float(ref_f[-1])))
-    assert hi < 1.5 * lo                                             # ... to the same loss level
+    # measured: 32 steps in both runs, accepted-point losses within 5.3e-3 of the reference's at every step
+    assert rel[0] < 1e-5 and rel.max() < 3e-2
+    assert my_f[-1] < 0.8 * my_f[0]                                  # the job makes progress ...
+    assert my_f[-1] == pytest.approx(ref_f[-1], rel=3e-2)            # ... to the reference's loss level
 
 
 @pytest.mark.parametrize("gram", [True, False])

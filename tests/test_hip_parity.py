@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from oracle import cpu_ref
-from hip_helpers import (BULK_RTOL, CW, GRAD_RTOL, SW, TERMS, TVW, assert_grad_close, check_rows,
+from hip_helpers import (BULK_RTOL, CW, GRAD_RTOL, NEAR_TIE, SW, TERMS, TVW, assert_grad_close, check_rows,
                          closure_vs_oracle_under_equal_decisions, dev, rel_l2, report, levels as _levels, setup as _setup,
                          oracle_targets)
 
@@ -137,35 +137,32 @@ def test_vgg_features_vs_reference_fixture(eng, golden):
     np.testing.assert_allclose(outs[4].cpu().numpy(), fx["out4_full"], rtol=1e-4, atol=1e-4)
 
 
-# Backward of the frozen network for injected output gradients: the flip-aware comparison of hip_helpers with a loose cap
-# on the whole (random injected gradients weight every unit alike, so one flipped deep unit weighs more than in a loss)
-assert_backward_close = functools.partial(assert_grad_close, cap=3e-2)
-
-
 @pytest.mark.parametrize("h,w", [(48, 80), (35, 51)])
 def test_vgg_backward_vs_autograd(eng, vgg_weights, golden, h, w):
+    """Backward of the frozen network for random injected output gradients (all six taps, and single taps) against the
+    oracle's autograd under the DEVICE pass's ReLU / pooling decisions (nst_vgg_activations -> cpu_ref.Decisions):
+    rel-L2 <= 2e-5 on the whole gradient.  Random injected gradients weight every unit alike, so under each side's OWN
+    decisions one flipped deep unit shows as 5e-3 on a 35x51 image (measured); that comparison is capped at 3e-2."""
     img = cpu_ref.synthetic_image(h, w, seed=3)
-    x = cpu_ref.prepare_img(img).requires_grad_(True)
-    outs = cpu_ref.vgg19_features(x, vgg_weights)
+    x0 = cpu_ref.prepare_img(img)
+    dec = cpu_ref.Decisions([a.cpu() for a in eng.vgg_activations(dev(x0))])
     g = torch.Generator().manual_seed(21)
-    gouts, loss = [], 0
-    for o in outs:
-        wgt = torch.randn(o.shape, generator=g) / o.numel()
-        gouts.append(wgt)
-        loss = loss + (o * wgt).sum()
-    loss.backward()
-    gx = eng.vgg_features_backward(dev(x.detach()), [dev(t) for t in gouts])
-    assert_backward_close(gx.cpu().numpy(), x.grad.numpy(), "all taps")
-    if (h, w) == (48, 80):     # the same quantity computed by the reference itself
-        assert_backward_close(gx.cpu().numpy(), golden("vgg_48x80")["grad"], "fixture")
-    # a single injected map (others absent)
-    for keep in (0, 4, 5):
-        x2 = x.detach().clone().requires_grad_(True)
-        o2 = cpu_ref.vgg19_features(x2, vgg_weights)
-        (o2[keep] * gouts[keep]).sum().backward()
-        only = [dev(gouts[i]) if i == keep else None for i in range(6)]
-        gx2 = eng.vgg_features_backward(dev(x.detach()), only)
-        assert_backward_close(gx2.cpu().numpy(), x2.grad.numpy(), f"tap {keep}")
+    gouts = [torch.randn(o.shape, generator=g) / o.numel() for o in cpu_ref.vgg19_features(x0, vgg_weights)]
+
+    def oracle(keep, decisions):
+        x = x0.clone().requires_grad_(True)
+        outs = cpu_ref.vgg19_features(x, vgg_weights, decisions)
+        sum((outs[i] * gouts[i]).sum() for i in keep).backward()
+        return x.grad.numpy()
+
+    for keep in ((0, 1, 2, 3, 4, 5), (0,), (4,), (5,)):
+        only = [dev(gouts[i]) if i in keep else None for i in range(6)]
+        gx = eng.vgg_features_backward(dev(x0), only).cpu().numpy()
+        e_forced, e_own = rel_l2(gx, oracle(keep, dec)), rel_l2(gx, oracle(keep, None))
+        report(f"vgg backward {h}x{w} taps {keep}: rel-L2 under equal decisions {e_forced:.2e}, under the oracle's own {e_own:.2e}")
+        assert e_forced < BULK_RTOL and e_own < 3e-2, (keep, e_forced, e_own)
+        if (h, w) == (48, 80) and len(keep) == 6:      # the same quantity computed by the reference itself
+            assert rel_l2(gx, golden("vgg_48x80")["grad"]) < 3e-2
 
 
 # ---------------------------------------------------------------- closure
@@ -310,16 +307,17 @@ def test_options_default_to_the_environment(vgg_weights, monkeypatch):
 
 @pytest.mark.parametrize("geo", [(63, 133, 1, 227, 293), (356, 151, 3, 356, 151), (103, 151, 3, 136, 329),
                                  (89, 320, 2, 89, 320), (290, 32, 2, 290, 32), (336, 77, 3, 104, 271)])
-def test_f16x2_vs_exact_f32_mfma_random_geometries(vgg_weights, geo):
-    """Odd sizes, foreign-size styles, 1-3 levels (geometries drawn by tools/fuzz_modes.py, which ran 40 of them):
-    the default closure (fp16-piece convolutions, batched levels, fused un-pooling, buffer-addressed epilogues on
-    interior tiles and the general form on edge tiles) against the same library's exact-f32-MFMA closure on the
-    per-level schedule.  An indexing bug shows as errors of order 1; arithmetic agrees to 1e-7 in the losses and
-    to the ReLU-flip noise in the gradient."""
+def test_random_geometries_vs_oracle(vgg_weights, geo):
+    """Odd sizes, foreign-size styles, 1-3 levels (geometries drawn by tools/fuzz_modes.py, which ran 40 of them): the
+    default closure (fp16-piece convolutions, batched levels, fused un-pooling, buffer-addressed epilogues on interior
+    tiles and the general form on edge tiles), the exact-f32-MFMA closure on the per-level schedule, and the f16x2
+    per-level launches in 16-row bands - each against the oracle under equal decisions (gradient 2e-5 on the whole).  An
+    indexing bug shows as errors of order 1."""
     from artstyletransfer_amd.engine import StyleEngine
     h, w, nlev, hs, ws = geo
     c, s = _levels(h, w, nlev, 1), _levels(hs, ws, nlev, 2)
-    x = dev(cpu_ref.prepare_img((0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(h, w, seed=9)).astype(np.float32)))
+    xt = cpu_ref.prepare_img((0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(h, w, seed=9)).astype(np.float32))
+    tg = oracle_targets(c, s, vgg_weights)
     res = []
     for opts in (dict(conv_mode="f32", batched=False, h2_band_rows=0),
                  dict(conv_mode="f16x2", batched=True, h2_band_rows=0),
@@ -327,7 +325,13 @@ def test_f16x2_vs_exact_f32_mfma_random_geometries(vgg_weights, geo):
         e = StyleEngine(vgg_weights, 0, **opts)
         try:
             _setup(e, c, s)
-            g, l = e.closure(x, 1e3, 4e5, 1e2)
+            # cap 1e-2 on the comparison under each side's OWN decisions: where a level is not an exact half of the one
+            # above (89 -> 44 rows), its flat regions become +-1 ulp noise of the down-sampling whose signs the
+            # total-variation term takes - measured 3.4e-3 of the whole gradient (1.7e-2 of the TV term alone), and
+            # 4e-7 once the signs are the device's
+            closure_vs_oracle_under_equal_decisions(e, xt, tg, vgg_weights, f"geometry {geo} {opts}", terms=(TERMS[0], TERMS[3]),
+                                                    cap=1e-2)
+            g, l = e.closure(dev(xt), 1e3, 4e5, 1e2)
             res.append((g.cpu().numpy(), l.cpu().numpy()))
         finally:
             e.close()
@@ -336,7 +340,6 @@ def test_f16x2_vs_exact_f32_mfma_random_geometries(vgg_weights, geo):
         np.testing.assert_allclose(l1[-1], l0[-1], rtol=1e-5)
         np.testing.assert_allclose(l1[:-1].reshape(nlev, 4)[:, 0], l0[:-1].reshape(nlev, 4)[:, 0], rtol=2e-5)
         assert np.isfinite(g1).all()
-        assert_grad_close(g1, g0, f"geometry {geo}")
     # the banded per-level launches compute what the batched launches compute
     np.testing.assert_allclose(res[2][1], res[1][1], rtol=1e-6)
     assert rel_l2(res[2][0], res[1][0]) < 1e-5
@@ -369,8 +372,9 @@ def test_hostile_operand_scales_vs_oracle(trial):
         try:
             _setup(e, c, s)
             # near-ties are judged against the layer's rms, and sigma-3 biases put a larger share of the units there
+            # measured under equal decisions: <= 2.1e-5 (the content term where conv4_2's weights are scaled by 2^-5 ... 2^-6)
             closure_vs_oracle_under_equal_decisions(e, xt, tg, w, f"hostile scales {trial} log2 {np.log2(scales).astype(int).tolist()} {opts}",
-                                                    terms=TERMS[:3], cap=5e-2)
+                                                    terms=TERMS[:3], grad_tol=1e-4, cap=5e-2)
         finally:
             e.close()
 
@@ -502,7 +506,30 @@ def test_full_size_job_properties(monkeypatch, levels_num):
         assert other.conv_mode() == "f32" and torch.equal(x2, x)
         g2, l2 = other.closure(x2, cw, sw, tvw)
         np.testing.assert_allclose(l2.cpu().numpy(), l0.cpu().numpy(), rtol=1e-5)
-        assert_grad_close(g2.cpu().numpy(), g0.cpu().numpy(), f"full size levels_num={n}: f16x2 vs f32")
+        e_modes = float((g2.double() - g0.double()).norm() / g0.double().norm())
+        # The two arithmetics may take different ReLU decisions only at near-ties: where exactly one of them has a unit
+        # on, that unit's value is within NEAR_TIE of zero (relative to the layer's rms).  Checked on the device, level
+        # by level (levels below 4 GiB per map), against the f16x2 engine rebuilt on the same job.
+        again, x3, _, _ = bench.build_job(n, 0, 0)
+        try:
+            again.closure(x3, cw, sw, tvw)
+            worst, share = 0.0, 0.0
+            for lvl in range(n):
+                if (x.shape[2] >> lvl) * (x.shape[3] >> lvl) > 2048 * 3072:
+                    continue
+                for layer in range(13):
+                    a, b = again.level_activation(lvl, layer), other.level_activation(lvl, layer)
+                    d = (a > 0) != (b > 0)
+                    if bool(d.any()):
+                        rms = float(b.double().pow(2).mean().sqrt())
+                        worst = max(worst, float(torch.maximum(a, b)[d].max()) / rms)
+                        share = max(share, float(d.float().mean()))
+                    del a, b, d
+        finally:
+            again.close()
+        report(f"full size levels_num={n}: f16x2 vs f32-MFMA gradient rel-L2 {e_modes:.2e}; their ReLU decisions differ at up to "
+               f"{share:.1e} of a layer's units, largest value at such a unit / rms {worst:.1e}")
+        assert e_modes < GRAD_RTOL and share < 1e-4 and worst < NEAR_TIE
     finally:
         other.close()
 
@@ -562,46 +589,68 @@ def test_stripe_and_mode_errors_are_reported(vgg_weights, monkeypatch):
 
 
 # ---------------------------------------------------------------- job set-up on the device (rows f-1 / f-2)
-@pytest.mark.parametrize("h,w,nh,nw", [(20, 30, 40, 60), (64, 96, 32, 48), (37, 53, 256, 367), (256, 383, 9, 13), (9, 13, 256, 384)])
-def test_device_resize_vs_host(eng, h, w, nh, nw):
+# Oracle: oracle/cv2_ref.py, the tap-by-tap restatement of the OpenCV operators that tests/test_oracle_cv2.py holds
+# against torch's bicubic kernel and scipy.ndimage (OpenCV itself is absent offline).  The device resize follows OpenCV's own
+# arithmetic: source coordinate formed in double and dropped to float, float weights.  That one rounding of a coordinate f
+# (half an ulp, 6e-8 f) moves the four weights by as much, i.e. the result by up to ~1e-7 * f * (pixel contrast).
+def _resize_atol(h, w):
+    return 2e-6 + 1.5e-7 * max(h, w)
+
+
+@pytest.mark.parametrize("h,w,nh,nw", [(20, 30, 40, 60), (64, 96, 32, 48), (37, 53, 256, 367), (256, 383, 9, 13), (9, 13, 256, 384),
+                                       (150, 200, 256, 341), (31, 17, 30, 18)])
+def test_device_resize_vs_oracle(eng, h, w, nh, nw):
+    from oracle import cv2_ref
     from artstyletransfer_amd import host_image
-    img = np.random.RandomState(h + w).rand(h, w, 3).astype(np.float32)
-    ref = host_image.bicubic_resize(img, nh, nw)
+    img = np.random.RandomState(h + w).rand(h, w, 3).astype(np.float32)         # white noise: the hardest contrast
     out = eng.resize(dev(torch.from_numpy(img)), nh, nw).cpu().numpy()
-    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6)
+    err = float(np.abs(out - cv2_ref.resize_cubic(img, nh, nw)).max())
+    report(f"device resize {h}x{w} -> {nh}x{nw}: max |diff| vs the oracle {err:.1e} (bound {_resize_atol(h, w):.1e})")
+    assert err <= _resize_atol(h, w)
+    # the host mirror (torch's fp32 kernel: coordinate formed in fp32, two roundings) agrees to twice that
+    np.testing.assert_allclose(out, host_image.bicubic_resize(img, nh, nw), rtol=0, atol=2 * _resize_atol(h, w))
 
 
-def test_device_pyramid_and_noise_init_vs_host(eng):
-    """The whole job set-up of neural_style_transfer(): pyramid levels, multi-granularity style noise under
-    Gaussian envelopes (same numpy RNG stream), Sobel blend weight, initial image - device vs host restatement."""
+def test_device_pyramid_and_noise_init_vs_oracle(eng):
+    """The whole job set-up of neural_style_transfer(): pyramid levels, multi-granularity style noise under Gaussian
+    envelopes (same numpy RNG stream), Sobel blend weight, initial image - device kernels against oracle/cv2_ref.py
+    (and against the host mirror the product's `resize` / `make_style_noise` helpers are)."""
+    from oracle import cv2_ref
     from artstyletransfer_amd import config, device_image, host_image
     cfg = config.Config()
     content = cpu_ref.synthetic_image(150, 200, seed=1)
     style = cpu_ref.synthetic_image(90, 140, seed=2)
     levels = 2
-    c_host = [host_image.resize_to_level(content, l) for l in (1, 0)]
-    s_host = [host_image.resize_to_level(style, l) for l in (1, 0)]
+    c_ref = [cv2_ref.resize_cubic(content, *cv2_ref.level_size(150, 200, l)) for l in (1, 0)]
+    s_ref = [cv2_ref.resize_cubic(style, *cv2_ref.level_size(90, 140, l)) for l in (1, 0)]
     cd, sd = device_image.upload(eng, content), device_image.upload(eng, style)
     c_dev, s_dev = device_image.pyramid(eng, cd, levels), device_image.pyramid(eng, sd, levels)
-    for a, b in zip(c_dev + s_dev, c_host + s_host):
+    for a, b in zip(c_dev + s_dev, c_ref + s_ref):
         assert tuple(a.shape) == b.shape
-        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=2e-6)
+        np.testing.assert_allclose(a.cpu().numpy(), b, rtol=0, atol=5e-6)         # smooth images
     args = (cfg.noise_factor, cfg.noise_levels, cfg.noise_levels_central_amplitude,
             cfg.noise_levels_peripheral_amplitude, cfg.noise_levels_dispersion)
+    ct, st = c_dev[0].cpu().numpy(), s_dev[0].cpu().numpy()
     for method in ("content+noise", "random", "style"):
         np.random.seed(7)
-        ref, tag_h = host_image.initial_image(method, content, style, c_host[0], s_host[0], 1, *args)
+        ref, tag_r = cv2_ref.initial_image(method, content, style, ct, st, 1, *args)
+        np.random.seed(7)
+        host, tag_h = host_image.initial_image(method, content, style, ct, st, 1, *args)
         np.random.seed(7)
         out, tag_d = device_image.initial_image(eng, method, cd, sd, c_dev[0], s_dev[0], 1, *args)
-        assert tag_h == tag_d and tuple(out.shape) == ref.shape
-        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=5e-6)
+        assert tag_r == tag_d == tag_h and tuple(out.shape) == ref.shape
+        err = float(np.abs(out.cpu().numpy() - ref).max())
+        report(f"device initial image '{method}' {ref.shape}: max |diff| vs the oracle {err:.1e}, vs the host mirror "
+               f"{float(np.abs(out.cpu().numpy() - host).max()):.1e}")
+        # the noise is permuted style pixels up-sampled from a 9 ... 36-wide grid: white-noise contrast at coordinates <= 768
+        assert err <= 2e-5
     # the noise map alone, tall image (the other branch of the grid-size rule) and a single negative granularity
     st = dev(torch.from_numpy(cpu_ref.synthetic_image(64, 48, seed=5)))
     np.random.seed(3)
-    ref = host_image.noise_map(st.cpu().numpy(), (96, 64, 3), (5, -2, 0), (0.3, 0.2, 0.2), (0.2, 0.1, 0.0), (0.2, 0.6, 0.3))
+    ref = cv2_ref.noise_map(st.cpu().numpy(), (96, 64, 3), (5, -2, 0), (0.3, 0.2, 0.2), (0.2, 0.1, 0.0), (0.2, 0.6, 0.3))
     np.random.seed(3)
     out = device_image.noise_map(eng, st, (96, 64, 3), (5, -2, 0), (0.3, 0.2, 0.2), (0.2, 0.1, 0.0), (0.2, 0.6, 0.3))
-    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=1e-5)
 
 
 # ---------------------------------------------------------------- drop-in entry points, end to end

@@ -53,6 +53,9 @@ def test_generator_closed_early_frees_the_optimiser(vgg_weights, monkeypatch):
         held.append(base - _free_bytes())
     pool = 202 * 12 * 256 * 384               # what one leaked optimiser would hold at least
     report(f"early-closed jobs: device bytes not returned after each of 3 jobs {held} (one history pool = {pool})")
+    # the library returns everything (tools/leak_probe.py: 0 bytes after every create / run / destroy cycle); what stays
+    # is torch's caching allocator keeping one 2 MB segment per stream of its 32-stream pool the first time a job's
+    # streams are used (bounded at 64 MB per device)
     assert max(held) < pool // 8
 
 
@@ -61,7 +64,7 @@ def test_failed_step_frees_the_optimiser(vgg_weights, monkeypatch):
     from artstyletransfer_amd import engine, neural_nets
     import neural_style_transfer as nst
     neural_nets.set_weights(vgg_weights)
-    c, s = levels(128, 192, 1, 1), levels(128, 192, 1, 2)
+    c, s = levels(256, 384, 1, 1), levels(256, 384, 1, 2)
     real_step = engine.PixelOptimizer.step
     calls = {"n": 0}
 
@@ -85,7 +88,8 @@ def test_failed_step_frees_the_optimiser(vgg_weights, monkeypatch):
         with pytest.raises(RuntimeError, match="injected"):
             asyncio.run(run())
     torch.cuda.empty_cache()
-    assert base - _free_bytes() < 4 << 20
+    # Adam state of one leaked job = 3 x 12*H*W bytes + the 160 MB workspace; torch's per-stream cache keeps <= 2 MB per job
+    assert base - _free_bytes() < 16 << 20
 
 
 def test_two_jobs_on_one_gpu_do_not_disturb_each_other(vgg_weights):
