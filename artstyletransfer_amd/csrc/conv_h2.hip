@@ -48,6 +48,9 @@ constexpr float LO_DOWN = 1.f / 2048.f;
 //       reads per 12 MFMAs), 1 -> 64 x 32 (64 registers, 6 reads per 6 MFMAs).
 // Shapes in use:
 //   <16, 128, 2, 32>  512 threads, 16x16 pixels x 128 channels               the 128-channel-multiple layers
+//   <16, 128, 4, 32>  256 threads, the same tile with ONE wave per SIMD and 64 x 128 wave tiles: 512 registers per
+//                     lane (the 256 accumulators live in AGPRs), 24 fragment reads per 48 MFMAs instead of 32
+//                     (nst_options.h2_wg256; tools/micro/tile_shapes.hip: +5 % on the bare MFMA + LDS stream)
 //   < 8, 128, 1, 32>  512 threads,  8x16 pixels x 128 channels               their under-filled launches
 //   < 8, 128, 2, 16>  256 threads,  8x16 pixels x 128 channels, 61 KB LDS    128-channel layers with Cin <= 128
 //   <16,  64, 2, 16>  256 threads, 16x16 pixels x  64 channels, 70 KB LDS    the 64-channel layers: TWO workgroups
@@ -83,7 +86,9 @@ struct H2Cfg {
     static_assert(B_UNITS % NT == 0, "every lane stages the same number of weight units (no predication)");
     // (the 256-thread shapes with 16-channel chunks fit twice on a CU; the 4-row shape is for launches with fewer
     // workgroups than CUs and may take more than half of it)
-    static_assert(LDS_BYTES <= ((NT == 512 || TH == 4) ? 160 : 80) * 1024, "LDS budget (two 256-thread workgroups share a CU)");
+    static_assert(LDS_BYTES <= ((NT == 512 || TH == 4 || NTW == 4) ? 160 : 80) * 1024, "LDS budget (two 256-thread workgroups share a CU)");
+    // waves per SIMD the register budget is cut for: the 64 x 128 wave tile takes the whole SIMD (256 VGPRs + 256 AGPRs)
+    static constexpr int WAVES_PER_EU = (NTW == 4) ? 1 : 2;
 };
 
 // Power-of-two scale that brings the recorded absmax (64 slots of non-negative float bit patterns) into
@@ -114,14 +119,22 @@ __device__ __forceinline__ void cut2x4(const f32x4 v, const float s, u32x2& hi, 
 
 }  // namespace
 
-// the whole workgroup program; (sp, ct) = spatial tile, output-channel tile of this workgroup
-template <int TH, int BN, int NTW, int KC, bool UNPOOL>
+// the whole workgroup program; (sp, ct) = spatial tile, output-channel tile of this workgroup.
+// M16 (KC == 32 shapes): the products run on v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16 - the same
+// FLOPs per fragment byte and per matrix-pipe cycle, but the chip holds a higher clock under it (this kernel is
+// power/clock bound: tools/micro/mfma_power.hip measures +7 % with this kernel's fragment traffic).  Staging and LDS
+// layout are shared; the fragment addressing, the MFMA order and the epilogues (accumulator layout: a lane holds 4
+// consecutive pixels of one channel instead of 16 pixel-rows of one channel) have a form of their own.
+template <int TH, int BN, int NTW, int KC, bool UNPOOL, bool M16>
 __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, const int ct, const int slot_seed) {
+    static_assert(!M16 || KC == 32, "the 16x16x32 form takes a whole 32-channel chunk per MFMA");
     using C = H2Cfg<TH, BN, NTW, KC>;
     constexpr int ROWB = C::ROWB, WROWB = C::WROWB, QP = C::QP, PIECEB = C::PIECEB, KS = C::KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned char* ldsA = smem;                          // 2 patch buffers
-    unsigned char* ldsB = smem + 2 * C::A_BYTES;         // 3 weight-slice buffers
+    // the three weight-slice buffers first: every fragment address of theirs is then ONE per-lane base + an immediate
+    // below 64 KiB (the ds_read offset field), instead of a base register per slice
+    unsigned char* ldsB = smem;                          // 3 weight-slice buffers
+    unsigned char* ldsA = smem + 3 * C::B_BYTES;         // 2 patch buffers
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -277,6 +290,82 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     };
     Frags F[2];
 
+    // ---- M16: v_mfma_f32_16x16x32_f16.  Lane (l15 = lane & 15, kg = lane >> 4) holds A[row l15][k = 8 kg + j] and
+    // B[k = 8 kg + j][col l15]; D[row = 4 kg + i][col = l15], i = 0..3.  M tile mt (0..3) = the 16 pixels of image row
+    // wm*4 + mt of the tile, N tile nt (0..2 NTW - 1) = 16 output channels: a lane's accumulator (mt, nt)[i] is pixel
+    // (row mt, column 4 kg + i), channel 16 nt + l15.  Fragments are handled as PAIRS of tiles (2 tiles x 2 pieces = 4
+    // ds_read_b128); a stage (K = 32: one tap of one chunk) is four quadrants (A pair, B pair) of 12 MFMAs each,
+    // walked as a snake so that consecutive quadrants share one pair, and the snake alternates direction from stage
+    // to stage: every pair is loaded one quadrant (12 MFMAs) before its first use into the register set that the
+    // previous quadrant released - 64 fragment registers in all, as in the 32x32 form.
+    constexpr int NT16 = 2 * NTW, NP = NTW;          // 16-channel tiles / pairs of them per wave
+    f32x4 am16[M16 ? 4 : 1][M16 ? NT16 : 1], ax16[M16 ? 4 : 1][M16 ? NT16 : 1];
+    if constexpr (M16) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < NT16; ++b)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { am16[a][b][r] = 0.f; ax16[a][b][r] = 0.f; }
+    }
+    const int kg = lane >> 4, l15 = lane & 15;
+    const int a16_off = (wm * 4) * C::PROWB + l15 * ROWB + kg * 16;
+    const int b16_off = (wn * 32 * NTW + l15) * ROWB + kg * 16;
+    struct Pair { f16x8 v[2][2]; };                  // [tile of the pair][piece]
+    auto read_a = [&](Pair& f, const unsigned char* abase, const int pair) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                f.v[j][s] = *reinterpret_cast<const f16x8*>(abase + a16_off + (2 * pair + j) * C::PROWB + s * PIECEB);
+    };
+    auto read_b = [&](Pair& f, const unsigned char* bbase, const int pair) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                f.v[j][s] = *reinterpret_cast<const f16x8*>(bbase + b16_off + (2 * pair + j) * 16 * ROWB + s * PIECEB);
+    };
+    // the 12 MFMAs of quadrant (A pair mp, B pair np): cross (lo x hi), main, cross (hi x lo) - the two MFMAs that
+    // accumulate into one cross accumulator are eight instructions apart
+    auto quad = [&](const Pair& a, const Pair& b, const int mp, const int np) {
+        if constexpr (M16) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    ax16[2 * mp + i][2 * np + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v[i][1], b.v[j][0], ax16[2 * mp + i][2 * np + j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    am16[2 * mp + i][2 * np + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v[i][0], b.v[j][0], am16[2 * mp + i][2 * np + j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    ax16[2 * mp + i][2 * np + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.v[i][0], b.v[j][1], ax16[2 * mp + i][2 * np + j], 0, 0, 0);
+        }
+    };
+    // pin one quadrant: its 12 MFMAs with `reads` fragment reads (4 or 8) spread between them
+    auto pin_quad = [&](const int reads) {
+        if (reads == 4) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+    };
+    Pair RA[2], RB[2];
+
     // ---- second K source: the Gram backward dF = F S (1 tap, fp32 weights cut here).  One stage per 32-channel
     // chunk; patch and weights alternate between two LDS buffers and are staged one stage ahead (global loads two
     // ahead), one barrier per stage.  Loads are buffer loads with loop-invariant per-lane offsets plus a scalar
@@ -344,10 +433,21 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             }
             const unsigned char* centre = ldsA + cb * C::A_BYTES + C::PROWB + ROWB;     // 1 tap: the centre of the patch
             const unsigned char* bcur = ldsB + cb * C::B_BYTES;
+            if constexpr (M16) {
+                read_a(RA[0], centre, 0);
+                read_a(RA[1], centre, 1);
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) request(F[ks], centre, bcur, ks);
+                for (int np = 0; np < NP; ++np) {
+                    read_b(RB[0], bcur, np);
+                    quad(RA[0], RB[0], 0, np);
+                    quad(RA[1], RB[0], 1, np);
+                }
+            } else {
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) multiply(F[ks]);
+                for (int ks = 0; ks < KS; ++ks) request(F[ks], centre, bcur, ks);
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) multiply(F[ks]);
+            }
             __syncthreads();
         }
     };
@@ -405,7 +505,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             store_b(ldsB + C::B_BYTES, r1, tid);
         }
         __syncthreads();
-        request(F[0], ldsA + tap_off(0), ldsB, 0);
+        if constexpr (M16) {
+            read_a(RA[0], ldsA + tap_off(0), 0);
+            read_b(RB[0], ldsB, 0);
+        } else {
+            request(F[0], ldsA + tap_off(0), ldsB, 0);
+        }
         // Two waves per SIMD: the later-dispatched half of an 8-wave workgroup (waves 4-7) loses issue arbitration to the
         // older half at the start of every stage.  One s_setprio for that half, once, before the loop (the condition
         // must be provably wave-uniform: s_setprio ignores EXEC): conv launches -2 % (A/B on one box); flipping the
@@ -440,7 +545,36 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
                 const unsigned char* bcur = ldsB + (t % 3) * C::B_BYTES;
                 const unsigned char* anxt = (t + 1 < 9) ? acur + tap_off(t + 1) : anext + tap_off(0);
                 const unsigned char* bnxt = ldsB + ((t + 1) % 3) * C::B_BYTES;
-                if (KS == 2) {
+                if constexpr (M16) {
+                    const unsigned char* aptr = acur + tap_off(t);
+                    const int sp_ = (PAR + t) & 1;           // a constant once the tap loop is unrolled
+                    if (NP == 2) {
+                        // sp_ = 0: (A0,B0) (A0,B1) (A1,B1) (A1,B0), entering with RA[0] = A0, RB[0] = B0;
+                        // sp_ = 1: (A0,B1) (A0,B0) (A1,B0) (A1,B1), entering with RA[0] = A0, RB[1] = B1
+                        const int b0 = sp_, b1 = sp_ ^ 1;     // first / second B pair of this stage's snake
+                        read_b(RB[b1], bcur, b1);                           // this stage's other B pair
+                        quad(RA[0], RB[b0], 0, b0);
+                        pin_quad(4);
+                        read_a(RA[1], aptr, 1);                             // this stage's A pair 1
+                        quad(RA[0], RB[b1], 0, b1);
+                        pin_quad(4);
+                        read_a(RA[0], anxt, 0);                             // next stage: A pair 0 (RA[0] is free)
+                        quad(RA[1], RB[b1], 1, b1);
+                        pin_quad(4);
+                        read_b(RB[b1], bnxt, b1);                           // next stage starts with B pair b1 (RB[b1] is free)
+                        quad(RA[1], RB[b0], 1, b0);
+                        pin_quad(4);
+                    } else {
+                        // one B pair: (A0,B0) (A1,B0); the B set alternates from stage to stage
+                        read_a(RA[1], aptr, 1);
+                        quad(RA[0], RB[sp_], 0, 0);
+                        pin_quad(4);
+                        read_a(RA[0], anxt, 0);
+                        read_b(RB[sp_ ^ 1], bnxt, 0);
+                        quad(RA[1], RB[sp_], 1, 0);
+                        pin_quad(8);
+                    }
+                } else if (KS == 2) {
                     // k-step 0, fetching k-step 1; then k-step 1, fetching the first fragments of the next stage
                     request(F[1], acur + tap_off(t), bcur, 1);
                     multiply(F[0]);
@@ -457,7 +591,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
                 __syncthreads();
             }
         };
-        if (KS == 2) {
+        if (KS == 2 && !M16) {
             for (int c = 0; c < nch; ++c) chunk(c, std::integral_constant<int, 0>{});
         } else {
             // 9 stages per chunk: the fragment sets swap roles from one chunk to the next (nch is even)
@@ -483,12 +617,21 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         tensor_scale(p.amax_w2, lane, sw2, iw2);
         gram_source(p.in2, p.Cin2, p.wt2_f32, sa2, sw2);
         const float ratio = (ia2 * sa1) * (iw2 * (1.f / w1_inv));
+        if constexpr (M16) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int b = 0; b < NTW; ++b)
+                for (int b = 0; b < NT16; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { accm[a][b][r] *= ratio; accx[a][b][r] *= ratio; }
+                    for (int r = 0; r < 4; ++r) { am16[a][b][r] *= ratio; ax16[a][b][r] *= ratio; }
+        } else {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < NTW; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { accm[a][b][r] *= ratio; accx[a][b][r] *= ratio; }
+        }
     }
     if (has_main) main_source(p.in, p.Cin, p.wt_h2, sa1);
 
@@ -502,6 +645,215 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             if (lane == 0) atomicMax(p.amax_out + ((slot_seed * (C::NT / 64) + wave) & (NST_AMAX_SLOTS - 1)), __float_as_uint(amax));
         }
     };
+
+    if constexpr (M16) {
+        // ======== epilogues of the 16x16x32 form.  Element (mt, nt, i) of a lane: pixel (y0 + wm*4 + mt, x0 + 4 kg + i),
+        // channel cg0 + 16 nt + l15.  A ReLU / arg-max bit word (bit = channel & 31) covers the two 16-channel tiles
+        // nt = 2 w, 2 w + 1: a ballot over one tile's register holds, for each of the four pixels 4 kg + i, the 16
+        // channel bits of that pixel in bits 16 kg .. 16 kg + 15.
+        const int cg0 = n0 + wn * 32 * NTW;
+        const float lo_clamp = p.relu ? 0.f : -__builtin_inff();
+        auto word_of = [&](const unsigned long long b_even, const unsigned long long b_odd) -> unsigned {
+            return (unsigned)((b_even >> (16 * kg)) & 0xFFFFull) | ((unsigned)((b_odd >> (16 * kg)) & 0xFFFFull) << 16);
+        };
+        const bool interior = (y0 + TH <= p.H) && (x0 + C::TW <= p.W);
+        const bool fwd_like = !p.bits_in && !p.addend;
+        const bool bwd_like = p.bits_in && !p.bits_out && !p.pool_out && !p.pcode_out;
+        if (interior && !p.mask && (fwd_like || bwd_like) && (size_t)p.H * p.W * p.Cout * 4 < 0xFFFFFF00ull) {
+            const unsigned out_bytes = (unsigned)((size_t)p.H * p.W * p.Cout * 4);
+            const unsigned bit_bytes = (unsigned)((size_t)p.H * p.W * words * 4);
+            const int colB = p.Cout * 4, rowB = p.W * colB;              // bytes per pixel / per image row
+            const int wcolB = words * 4, wrowB = p.W * wcolB;            // the same for the bit-mask words
+            const int pix0 = (y0 + wm * 4) * p.W + x0 + 4 * kg;          // this lane's first pixel
+            const unsigned vbase = (unsigned)pix0 * (unsigned)colB + (unsigned)(cg0 + l15) * 4u;
+            const unsigned wbase = (unsigned)pix0 * (unsigned)wcolB + (unsigned)(cg0 >> 5) * 4u;
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
+            if (bwd_like) {
+                const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.bits_in), 0, bit_bytes, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.addend), 0, p.addend ? out_bytes : 0u, 0x00020000);
+                // all mask words of the tile first (the fragment registers are free now), then arithmetic and stores
+                unsigned wv[4][4][NTW];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (NTW == 2) {
+                            const u32x2 w2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_bits, wbase, mt * wrowB + i * wcolB, 0));
+                            wv[mt][i][0] = w2[0];
+                            wv[mt][i][NTW - 1] = w2[1];
+                        } else {
+                            wv[mt][i][0] = __builtin_amdgcn_raw_buffer_load_b32(rs_bits, wbase, mt * wrowB + i * wcolB, 0);
+                        }
+                    }
+#pragma unroll
+                for (int nt = 0; nt < NT16; ++nt) {
+                    const float bv = p.bias ? p.bias[cg0 + nt * 16 + l15] : 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        float ad[4] = {0.f, 0.f, 0.f, 0.f};
+                        if (p.addend) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                ad[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, vbase, mt * rowB + i * colB + nt * 64, 0));
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v = fmaf(ax16[mt][nt][i], LO_DOWN, am16[mt][nt][i]) * inv + bv;
+                            v = fmaxf(v + ad[i], lo_clamp);              // (+ 0 without an addend: -0 sums as in the general form)
+                            v = ((wv[mt][i][nt >> 1] >> ((nt & 1) * 16 + l15)) & 1u) ? v : 0.f;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, vbase, mt * rowB + i * colB + nt * 64, 0);
+                            amax = fmaxf(amax, fabsf(v));
+                        }
+                    }
+                }
+            } else {
+                const int PW2 = p.W >> 1;
+                const unsigned pool_bytes = (unsigned)((size_t)(p.H >> 1) * PW2 * p.Cout * 4);
+                const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(p.bits_out, 0, p.bits_out ? bit_bytes : 0u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc(p.pool_out, 0, p.pool_out ? pool_bytes : 0u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_code = __builtin_amdgcn_make_buffer_rsrc(
+                    p.pcode_out, 0, p.pcode_out ? (unsigned)((size_t)(p.H >> 1) * PW2 * words * 16) : 0u, 0x00020000);
+                // one lane per pixel column group writes the bit words; the others carry an offset beyond the buffer (dropped)
+                const unsigned wlane = (l15 == 0) ? wbase : 0xFFFFFF00u;
+                const int ppix0 = ((y0 + wm * 4) >> 1) * PW2 + ((x0 + 4 * kg) >> 1);
+                const unsigned pbase = (unsigned)ppix0 * (unsigned)colB + (unsigned)(cg0 + l15) * 4u;
+                const unsigned cbase = (l15 == 0) ? ((unsigned)ppix0 * (unsigned)words + (unsigned)(cg0 >> 5)) * 16u : 0xFFFFFF00u;
+#pragma unroll
+                for (int nt = 0; nt < NT16; ++nt) {
+                    const float bv = p.bias ? p.bias[cg0 + nt * 16 + l15] : 0.f;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float v = fmaf(ax16[mt][nt][i], LO_DOWN, am16[mt][nt][i]) * inv + bv;
+                            v = fmaxf(v, lo_clamp);
+                            am16[mt][nt][i] = v;
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, vbase, mt * rowB + i * colB + nt * 64, 0);
+                            amax = fmaxf(amax, fabsf(v));
+                        }
+                }
+                if (p.bits_out) {
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int w = 0; w < NTW; ++w) {
+                                const unsigned long long b0 = __ballot(am16[mt][2 * w][i] > 0.f), b1 = __ballot(am16[mt][2 * w + 1][i] > 0.f);
+                                __builtin_amdgcn_raw_buffer_store_b32(word_of(b0, b1), rs_bits, wlane, mt * wrowB + i * wcolB + w * 4, 0);
+                            }
+                }
+                if (p.pool_out) {
+                    // 2x2/2 max pool: window = image rows (mt, mt + 1), mt even, x columns (i, i + 1), i even - all four in this lane
+#pragma unroll
+                    for (int mt = 0; mt < 4; mt += 2)
+#pragma unroll
+                        for (int i = 0; i < 4; i += 2) {
+                            const int poff = (mt >> 1) * PW2 + (i >> 1);
+                            unsigned long long code[NTW][4][2];
+#pragma unroll
+                            for (int nt = 0; nt < NT16; ++nt) {
+                                const float e0 = am16[mt][nt][i], e1 = am16[mt][nt][i + 1], e2 = am16[mt + 1][nt][i], e3 = am16[mt + 1][nt][i + 1];
+                                const float mx = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3));
+                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, mx), rs_pool, pbase, poff * colB + nt * 64, 0);
+                                if (p.pcode_out) {
+                                    int pos = 0;
+                                    float best = e0;
+                                    if (e1 > best) { best = e1; pos = 1; }
+                                    if (e2 > best) { best = e2; pos = 2; }
+                                    if (e3 > best) { best = e3; pos = 3; }
+                                    const bool live = best > 0.f;
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) code[nt >> 1][q][nt & 1] = __ballot(live && pos == q);
+                                }
+                            }
+                            if (p.pcode_out) {
+#pragma unroll
+                                for (int w = 0; w < NTW; ++w)
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q)
+                                        __builtin_amdgcn_raw_buffer_store_b32(word_of(code[w][q][0], code[w][q][1]), rs_code, cbase,
+                                                                              (poff * words + w) * 16 + q * 4, 0);
+                            }
+                        }
+                }
+            }
+            record_amax();
+            return;
+        }
+        // ---- general epilogue of the 16x16x32 form (edge tiles, fp32 masks, tensors from 4 GiB up)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int y = y0 + wm * 4 + mt;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int x = x0 + 4 * kg + i;
+                const bool inb = (y < p.H && x < p.W);
+                const size_t pix = (size_t)y * p.W + x;
+#pragma unroll
+                for (int nt = 0; nt < NT16; ++nt) {
+                    const int co = cg0 + nt * 16 + l15;
+                    const size_t idx = pix * p.Cout + co;
+                    float v = fmaf(ax16[mt][nt][i], LO_DOWN, am16[mt][nt][i]) * inv + (p.bias ? p.bias[co] : 0.f);
+                    if (p.addend && inb) v += p.addend[idx];
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.bits_in) {
+                        const unsigned wv = inb ? p.bits_in[pix * words + (co >> 5)] : 0u;
+                        v = ((wv >> (co & 31)) & 1u) ? v : 0.f;
+                    } else if (p.mask) {
+                        v = (inb && p.mask[idx] > 0.f) ? v : 0.f;
+                    }
+                    am16[mt][nt][i] = v;
+                    if (inb) {
+                        p.out[idx] = v;
+                        amax = fmaxf(amax, fabsf(v));
+                    }
+                }
+                if (p.bits_out) {
+#pragma unroll
+                    for (int w = 0; w < NTW; ++w) {
+                        const unsigned long long b0 = __ballot(am16[mt][2 * w][i] > 0.f), b1 = __ballot(am16[mt][2 * w + 1][i] > 0.f);
+                        if (l15 == 0 && inb) p.bits_out[pix * words + (cg0 >> 5) + w] = word_of(b0, b1);
+                    }
+                }
+            }
+        }
+        if (p.pool_out) {
+            const int PH2 = p.H >> 1, PW2 = p.W >> 1;
+#pragma unroll
+            for (int mt = 0; mt < 4; mt += 2)
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    const int py = (y0 + wm * 4 + mt) >> 1, px = (x0 + 4 * kg + i) >> 1;
+                    const bool inw = (py < PH2 && px < PW2);
+                    unsigned long long code[NTW][4][2];
+#pragma unroll
+                    for (int nt = 0; nt < NT16; ++nt) {
+                        const float e0 = am16[mt][nt][i], e1 = am16[mt][nt][i + 1], e2 = am16[mt + 1][nt][i], e3 = am16[mt + 1][nt][i + 1];
+                        const float mx = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3));
+                        if (inw) p.pool_out[((size_t)py * PW2 + px) * p.Cout + cg0 + nt * 16 + l15] = mx;
+                        int pos = 0;
+                        float best = e0;
+                        if (e1 > best) { best = e1; pos = 1; }
+                        if (e2 > best) { best = e2; pos = 2; }
+                        if (e3 > best) { best = e3; pos = 3; }
+                        const bool live = best > 0.f;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) code[nt >> 1][q][nt & 1] = __ballot(live && pos == q);
+                    }
+                    if (p.pcode_out) {
+#pragma unroll
+                        for (int w = 0; w < NTW; ++w)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (l15 == 0 && inw)
+                                    p.pcode_out[(((size_t)py * PW2 + px) * words + (cg0 >> 5) + w) * 4 + q] = word_of(code[w][q][0], code[w][q][1]);
+                    }
+                }
+        }
+        record_amax();
+        return;
+    }
 
     // ---- fast epilogue: a tile that lies inside the image (every tile when H, W are multiples of 16).  No bounds
     // tests; every access is a buffer instruction = per-lane byte offset fixed for the whole epilogue + a scalar
@@ -538,7 +890,11 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        if (NTW == 2) {
+                        if (NTW == 4) {
+                            const u32x4 w4 = __builtin_amdgcn_raw_buffer_load_b128(rs_bits, wbase, soff(mt, r, wrowB, wcolB), 0);
+#pragma unroll
+                            for (int k = 0; k < NTW; ++k) wv[mt][r][k] = w4[k & 3];
+                        } else if (NTW == 2) {
                             const u32x2 w2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_bits, wbase, soff(mt, r, wrowB, wcolB), 0));
                             wv[mt][r][0] = w2[0];
                             wv[mt][r][NTW - 1] = w2[1];
@@ -746,16 +1102,16 @@ __device__ __forceinline__ int xcd_contiguous(const int b, const int grid) {
 #endif
 }
 
-template <int TH, int BN, int NTW, int KC, bool UNPOOL>
-__global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_kernel(ConvParams p) {
+template <int TH, int BN, int NTW, int KC, bool UNPOOL, bool M16>
+__global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), (H2Cfg<TH, BN, NTW, KC>::WAVES_PER_EU)) void conv_h2_kernel(ConvParams p) {
     const int n_ct = p.Cout / BN;
     const int t = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-    conv_h2_body<TH, BN, NTW, KC, UNPOOL>(p, t / n_ct, t % n_ct, blockIdx.x);
+    conv_h2_body<TH, BN, NTW, KC, UNPOOL, M16>(p, t / n_ct, t % n_ct, blockIdx.x);
 }
 
 // One launch = one layer over several images (the pyramid levels of a closure), see conv_bf3.hip.
-template <int TH, int BN, int NTW, int KC, bool UNPOOL>
-__global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_batch_kernel(ConvBatch b) {
+template <int TH, int BN, int NTW, int KC, bool UNPOOL, bool M16>
+__global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), (H2Cfg<TH, BN, NTW, KC>::WAVES_PER_EU)) void conv_h2_batch_kernel(ConvBatch b) {
     const int n_ct = b.Cout / BN;
     const int t = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
     const int sp_all = t / n_ct;
@@ -772,17 +1128,25 @@ __global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), 2) void conv_h2_batch
     p.amax_in = im.amax_in; p.amax_in2 = im.amax_in2; p.amax_w2 = im.amax_w2; p.amax_out = im.amax_out;
     p.pcode_in = im.pcode_in; p.pcode_out = im.pcode_out;
     p.in2_row0 = im.in2_row0; p.in2_rows = im.in2_rows; p.ty0 = 0;
-    conv_h2_body<TH, BN, NTW, KC, UNPOOL>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), t % n_ct, blockIdx.x);
+    conv_h2_body<TH, BN, NTW, KC, UNPOOL, M16>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), t % n_ct, blockIdx.x);
 }
 
-template <int TH, int BN, int NTW, int KC, bool UNPOOL>
-static hipError_t init_one() {
+template <int TH, int BN, int NTW, int KC, bool UNPOOL, bool M16>
+static hipError_t init_form() {
     constexpr int lds = H2Cfg<TH, BN, NTW, KC>::LDS_BYTES;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_kernel<TH, BN, NTW, KC, UNPOOL>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_kernel<TH, BN, NTW, KC, UNPOOL, M16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_batch_kernel<TH, BN, NTW, KC, UNPOOL>),
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_batch_kernel<TH, BN, NTW, KC, UNPOOL, M16>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+template <int TH, int BN, int NTW, int KC, bool UNPOOL>
+static hipError_t init_one() {
+    hipError_t e = init_form<TH, BN, NTW, KC, UNPOOL, false>();
+    if constexpr (KC == 32 && NTW <= 2) {
+        if (e == hipSuccess) e = init_form<TH, BN, NTW, KC, UNPOOL, true>();
+    }
+    return e;
 }
 
 hipError_t conv_h2_init_device() {
@@ -796,31 +1160,53 @@ hipError_t conv_h2_init_device() {
     if (e == hipSuccess) e = init_one<8, 128, 2, 16, true>();
     if (e == hipSuccess) e = init_one<4, 128, 1, 32, false>();
     if (e == hipSuccess) e = init_one<4, 128, 1, 32, true>();
+    if (e == hipSuccess) e = init_one<16, 128, 4, 32, false>();
+    if (e == hipSuccess) e = init_one<16, 128, 4, 32, true>();
     return e;
 }
 
 // a 128-channel launch whose 16-row tiles cannot fill 256 CUs twice over uses 8-row tiles, and 4-row tiles (256
 // threads, two workgroups per CU) when even those leave most of the chip idle: the deep layers of small jobs, whose
 // few workgroups each walk the whole K = 4 608 - the launch lasts as long as ONE workgroup does
-static int h2_tile_rows(int Cout, long blocks16) {
+static int h2_tile_rows(int Cout, long blocks16, int forced = 0) {
     if (Cout % 128 != 0) return 16;
+    if (forced == 4 || forced == 8 || forced == 16) return forced;      // nst_options.h2_tile_rows (experiments)
     if (blocks16 < 100) return 4;
     return blocks16 < 400 ? 8 : 16;
 }
 
+// The 16x16x32 form exists for the 32-channel-chunk shapes.  `mfma16` = nst_options.h2_mfma16: 1 (default) = on the
+// 8-row shape (64 x 32 wave tiles, 186 registers: +6 ... 11 % per launch, L=1 closure +1.6 %); 2 = on every shape it
+// exists for - slower on the 4-row shape (L=0 closure -3 %) and on the 64 x 64 wave-tile shape, where it needs ~20
+// registers more than the 256 a wave has at two waves per SIMD: the patch staging registers spill inside the K loop and
+// the launch is 5-20 % SLOWER (profiles/r02_mfma_shape_experiments.txt); 0 = off.
 template <int TH, int BN, int NTW, int KC>
 static void launch_batch_cfg(const ConvBatch& b, int blocks, hipStream_t stream) {
     constexpr int lds = H2Cfg<TH, BN, NTW, KC>::LDS_BYTES;
     constexpr int nt = H2Cfg<TH, BN, NTW, KC>::NT;
-    if (b.unpool) hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, true>), dim3(blocks), dim3(nt), lds, stream, b);
-    else hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, false>), dim3(blocks), dim3(nt), lds, stream, b);
+    if constexpr (KC == 32 && NTW <= 2) {
+        if (b.mfma16 >= 2 || (b.mfma16 == 1 && TH == 8)) {
+            if (b.unpool) hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, true, true>), dim3(blocks), dim3(nt), lds, stream, b);
+            else hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, false, true>), dim3(blocks), dim3(nt), lds, stream, b);
+            return;
+        }
+    }
+    if (b.unpool) hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, true, false>), dim3(blocks), dim3(nt), lds, stream, b);
+    else hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, false, false>), dim3(blocks), dim3(nt), lds, stream, b);
 }
 template <int TH, int BN, int NTW, int KC>
 static void launch_single_cfg(const ConvParams& p, int blocks, hipStream_t stream) {
     constexpr int lds = H2Cfg<TH, BN, NTW, KC>::LDS_BYTES;
     constexpr int nt = H2Cfg<TH, BN, NTW, KC>::NT;
-    if (p.pcode_in) hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW, KC, true>), dim3(blocks), dim3(nt), lds, stream, p);
-    else hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW, KC, false>), dim3(blocks), dim3(nt), lds, stream, p);
+    if constexpr (KC == 32 && NTW <= 2) {
+        if (p.mfma16 >= 2 || (p.mfma16 == 1 && TH == 8)) {
+            if (p.pcode_in) hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW, KC, true, true>), dim3(blocks), dim3(nt), lds, stream, p);
+            else hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW, KC, false, true>), dim3(blocks), dim3(nt), lds, stream, p);
+            return;
+        }
+    }
+    if (p.pcode_in) hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW, KC, true, false>), dim3(blocks), dim3(nt), lds, stream, p);
+    else hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW, KC, false, false>), dim3(blocks), dim3(nt), lds, stream, p);
 }
 
 static bool h2_operands_ok(const void* wt, const unsigned* amax_in, int Cin, int Cout, const float* in2, const float* wt2,
@@ -846,7 +1232,7 @@ hipError_t launch_conv_h2_batch(const ConvBatch& b0, hipStream_t stream) {
         blocks16 += (long)((im.H + 15) / 16) * ((im.W + 15) / 16) * (b.Cout / 128);
     }
     const bool shortk = wide && b.Cin > 0 && b.Cin <= NST_H2_SHORTK_CIN;      // 8-row tiles, two workgroups per CU
-    const int th = shortk ? 8 : h2_tile_rows(b.Cout, blocks16), bn = wide ? 128 : 64;
+    const int th = shortk ? 8 : h2_tile_rows(b.Cout, blocks16, b.tile_rows), bn = wide ? 128 : 64;
     int tiles = 0;
     for (int i = 0; i < b.n; ++i) {
         b.img[i].tiles_x = (b.img[i].W + 15) / 16;
@@ -858,6 +1244,7 @@ hipError_t launch_conv_h2_batch(const ConvBatch& b0, hipStream_t stream) {
     else if (shortk) launch_batch_cfg<8, 128, 2, 16>(b, blocks, stream);
     else if (th == 4) launch_batch_cfg<4, 128, 1, 32>(b, blocks, stream);
     else if (th == 8) launch_batch_cfg<8, 128, 1, 32>(b, blocks, stream);
+    else if (b.wg256) launch_batch_cfg<16, 128, 4, 32>(b, blocks, stream);
     else launch_batch_cfg<16, 128, 2, 32>(b, blocks, stream);
     return hipGetLastError();
 }
@@ -870,7 +1257,7 @@ hipError_t launch_conv_h2(const ConvParams& p0, hipStream_t stream) {
     const bool wide = (p.Cout % 128 == 0);
     const long blocks16 = (long)((p.H + 15) / 16) * ((p.W + 15) / 16) * (p.Cout / 128);
     const bool shortk = wide && p.Cin > 0 && p.Cin <= NST_H2_SHORTK_CIN;
-    const int th = shortk ? 8 : h2_tile_rows(p.Cout, blocks16), bn = wide ? 128 : 64;
+    const int th = shortk ? 8 : h2_tile_rows(p.Cout, blocks16, p.tile_rows), bn = wide ? 128 : 64;
     p.tiles_x = (p.W + 15) / 16;
     // The kernels address with 32-bit buffer offsets.  A launch whose tensors reach 4 GiB runs in bands of output rows
     // (multiples of 16, so tiles and pooling windows stay aligned): every tensor pointer is moved to the band's first
@@ -911,6 +1298,7 @@ hipError_t launch_conv_h2(const ConvParams& p0, hipStream_t stream) {
         else if (shortk) launch_single_cfg<8, 128, 2, 16>(q, blocks, stream);
         else if (th == 4) launch_single_cfg<4, 128, 1, 32>(q, blocks, stream);
         else if (th == 8) launch_single_cfg<8, 128, 1, 32>(q, blocks, stream);
+        else if (q.wg256) launch_single_cfg<16, 128, 4, 32>(q, blocks, stream);
         else launch_single_cfg<16, 128, 2, 32>(q, blocks, stream);
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

@@ -101,6 +101,9 @@ struct nst_ctx {
     int conv_mode = 2;
     int band_rows = 0;          // nst_options.h2_band_rows (0 = bands only for tensors beyond 4 GiB)
     int lbfgs_gram = 1;         // nst_options.lbfgs_gram
+    int mfma16 = 1;             // nst_options.h2_mfma16
+    int wg256 = 0;              // nst_options.h2_wg256
+    int tile_rows = 0;          // nst_options.h2_tile_rows
     hipEvent_t tail = nullptr;  // recorded after the last launch that touches context-owned memory: what
                                 // nst_job_configure / nst_ctx_destroy wait for instead of the whole device
     int batched = 1;            // 1: one conv launch per layer covering every pyramid level (one stream)
@@ -348,7 +351,7 @@ int forward(nst_ctx* ctx, ActSet& a, const float* x, int h, int w, hipStream_t s
             p.wt_h2 = ctx->wf_h2[l]; p.wt_h2_inv = ctx->wf_h2_inv[l];
             p.amax_in = amax_act(a, l - 1);       // the pooled map's maximum is its source's
             p.amax_out = amax_act(a, l);
-            p.band_rows = ctx->band_rows;
+            p.band_rows = ctx->band_rows; p.mfma16 = ctx->mfma16; p.wg256 = ctx->wg256; p.tile_rows = ctx->tile_rows;
         }
         const int pa = pool_index_after(l);
         const bool fuse = bf3_unsplit(ctx, p);        // the epilogue extras exist in the unsplit bf3 kernel only
@@ -422,7 +425,7 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
             p.wt_h2 = ctx->wd_h2[l]; p.wt_h2_inv = ctx->wd_h2_inv[l];
             p.amax_in = amax_grad(a, l);
             p.amax_out = amax_grad(a, l - 1);     // when un-pooled next, this bounds the un-pooled gradient too
-            p.band_rows = ctx->band_rows;
+            p.band_rows = ctx->band_rows; p.mfma16 = ctx->mfma16; p.wg256 = ctx->wg256; p.tile_rows = ctx->tile_rows;
         }
         if (pk >= 0) {
             {
@@ -544,7 +547,7 @@ int batched_forward(nst_ctx* ctx, const float* const* xi, const int* lv, int n, 
         const int pk = pool_index_after(l - 1), pa = pool_index_after(l);
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wf_bf[l]; b.bias = ctx->bias[l]; b.Cin = kCin[l]; b.Cout = kCout[l]; b.relu = 1;
-        b.wt_h2 = ctx->wf_h2[l]; b.wt_h2_inv = ctx->wf_h2_inv[l];
+        b.wt_h2 = ctx->wf_h2[l]; b.wt_h2_inv = ctx->wf_h2_inv[l]; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows;
         double flops = 0;
         for (int k = 0; k < n; ++k) {
             ActSet& a = ctx->lv[lv[k]].acts;
@@ -619,7 +622,7 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
         // its own (no 3x3 part), one launch for all levels; its epilogue applies the ReLU mask and records the absmax
         const int l = NL - 1;
         ConvBatch b{};
-        b.n = n; b.Cin = 0; b.Cout = kCout[l]; b.Cin2 = kCout[l]; b.relu = 0; b.wt_h2_inv = 1.f;
+        b.n = n; b.Cin = 0; b.Cout = kCout[l]; b.Cin2 = kCout[l]; b.relu = 0; b.wt_h2_inv = 1.f; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows;
         double flops = 0;
         for (int k = 0; k < n; ++k) {
             LevelWs& L = ctx->lv[lv[k]];
@@ -651,7 +654,7 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
         for (int q = 0; q < 5; ++q) if (kStyleLayer[q] == m) style_q = q;
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wd_bf[l]; b.bias = nullptr; b.Cin = kCout[l]; b.Cout = kCin[l]; b.relu = 0;
-        b.wt_h2 = ctx->wd_h2[l]; b.wt_h2_inv = ctx->wd_h2_inv[l];
+        b.wt_h2 = ctx->wd_h2[l]; b.wt_h2_inv = ctx->wd_h2_inv[l]; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows;
         // f16x2: when a max-pool follows layer l, cur[] holds the gradient w.r.t. the POOLED map and this launch's
         // loader un-pools it through the arg-max code (no un-pool kernel, no full-size gradient round trip)
         const int pl = pool_index_after(l);
@@ -814,6 +817,7 @@ void nst_options_default(nst_options* o) {
     if (!o) return;
     o->struct_size = (int)sizeof(nst_options);
     o->conv_mode = -1; o->batched = -1; o->single_stream = -1; o->use_graph = -1; o->h2_band_rows = -1; o->lbfgs_gram = -1;
+    o->h2_mfma16 = -1; o->h2_wg256 = -1; o->h2_tile_rows = -1;
 }
 
 int nst_ctx_create(int device, const float* const* weights, const float* const* biases, nst_ctx** out) {
@@ -859,6 +863,9 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
     ctx->single_stream = (opts.single_stream >= 0 ? opts.single_stream : env_flag("NST_SINGLE_STREAM", 0)) != 0;
     ctx->band_rows = opts.h2_band_rows >= 0 ? opts.h2_band_rows : env_flag("NST_H2_BAND_ROWS", 0);
     ctx->lbfgs_gram = (opts.lbfgs_gram >= 0 ? opts.lbfgs_gram : env_flag("NST_LBFGS_GRAM", 1)) ? 1 : 0;
+    ctx->mfma16 = opts.h2_mfma16 >= 0 ? opts.h2_mfma16 : env_flag("NST_H2_MFMA16", 1);
+    ctx->wg256 = (opts.h2_wg256 >= 0 ? opts.h2_wg256 : env_flag("NST_H2_WG256", 0)) ? 1 : 0;
+    ctx->tile_rows = opts.h2_tile_rows >= 0 ? opts.h2_tile_rows : env_flag("NST_H2_TILE_ROWS", 0);
     if (ctx->use_graph && hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "stream creation failed"; return bail(NST_E_HIP); }
     if (e != hipSuccess) { ctx->err = std::string("kernel attribute setup: ") + hipGetErrorString(e); return bail(NST_E_HIP); }
 

@@ -46,6 +46,9 @@ struct ConvParams {
     int in2_row0, in2_rows;    // in2_rows > 0: the second source contributes on output rows [in2_row0, in2_row0 + in2_rows) only
     int ty0;                   // first tile row of this launch (filled by the launcher: tensors from 4 GiB up run in row bands)
     int band_rows;             // conv_h2: >= 16 forces row bands of that many rows (nst_options.h2_band_rows; 0 = only when needed)
+    int mfma16;                // conv_h2: the 32-channel-chunk shapes run on v_mfma_f32_16x16x32_f16 (nst_options.h2_mfma16)
+    int wg256;                 // conv_h2: the 16x16 x 128 tile as 4 waves of 64 x 128 (nst_options.h2_wg256)
+    int tile_rows;             // conv_h2: 4 / 8 / 16 forces that tile height on the 128-channel shapes (nst_options.h2_tile_rows)
 };
 
 constexpr int NST_AMAX_SLOTS = 64;
@@ -85,6 +88,7 @@ struct ConvBatch {
     const void* wt_h2;       // conv_h2 only
     float wt_h2_inv;
     int unpool;              // every image's `in` is a pooled gradient to be un-pooled through pcode_in
+    int mfma16, wg256, tile_rows;   // conv_h2: see ConvParams
 };
 
 // conv_mfma.hip

@@ -37,9 +37,11 @@ class StyleEngine:
 
     def __init__(self, weights: Sequence[Tuple[torch.Tensor, torch.Tensor]], device: int | str | torch.device = 0,
                  conv_mode: Optional[str] = None, batched: Optional[bool] = None, single_stream: Optional[bool] = None,
-                 use_graph: Optional[bool] = None, h2_band_rows: Optional[int] = None, lbfgs_gram: Optional[bool] = None):
+                 use_graph: Optional[bool] = None, h2_band_rows: Optional[int] = None, lbfgs_gram: Optional[bool] = None,
+                 h2_mfma16: Optional[bool] = None, h2_wg256: Optional[bool] = None,
+                 h2_tile_rows: Optional[int] = None):
         """Options (nst_options): None = environment variable (NST_CONV, NST_BATCH, NST_SINGLE_STREAM, NST_GRAPH,
-        NST_H2_BAND_ROWS, NST_LBFGS_GRAM; read once, here) and otherwise the default (f16x2, batched, ...)."""
+        NST_H2_BAND_ROWS, NST_LBFGS_GRAM, NST_H2_MFMA16; read once, here) and otherwise the default (f16x2, batched, ...)."""
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise NstError("no GPU visible: the style-transfer hot path runs only on the HIP device")
@@ -61,7 +63,8 @@ class StyleEngine:
                 raise NstError(f"conv_mode must be one of {sorted(_lib.CONV_MODES)}")
             opts.conv_mode = _lib.CONV_MODES[conv_mode]
         for name, val in (("batched", batched), ("single_stream", single_stream), ("use_graph", use_graph),
-                          ("h2_band_rows", h2_band_rows), ("lbfgs_gram", lbfgs_gram)):
+                          ("h2_band_rows", h2_band_rows), ("lbfgs_gram", lbfgs_gram), ("h2_mfma16", h2_mfma16),
+                          ("h2_wg256", h2_wg256), ("h2_tile_rows", h2_tile_rows)):
             if val is not None:
                 setattr(opts, name, int(val))
         ctx = C.c_void_p()

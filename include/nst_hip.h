@@ -74,6 +74,16 @@ typedef struct nst_options {
                              4 GiB take, forced onto small images); -1: env NST_H2_BAND_ROWS, default 0 = only when needed */
     int lbfgs_gram;       /* 1: L-BFGS direction from inner products (two passes over the history); 0: the sequential
                              recursion; -1: env NST_LBFGS_GRAM, default 1 */
+    int h2_mfma16;        /* f16x2 convolutions with 32-channel chunks: v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16
+                             (same products, same accumulation chains per output; the chip clocks higher under it): 0 = never,
+                             1 = on the 8-row x 128-channel shape (under-filled launches: +6 ... 11 % per launch),
+                             2 = on every 32-channel-chunk shape (slower on the others; kept for experiments);
+                             -1: env NST_H2_MFMA16, default 1 */
+    int h2_wg256;         /* f16x2 convolutions, the 16x16-pixel x 128-channel tile: 1 = 256-thread workgroups, one wave per SIMD
+                             with a 64 x 128 wave tile (accumulators in AGPRs), 0 = 512 threads with 64 x 64 wave tiles;
+                             -1: env NST_H2_WG256, default 0 */
+    int h2_tile_rows;     /* f16x2 convolutions with 128-channel tiles and 32-channel chunks: 4 / 8 / 16 = pixel rows per workgroup tile,
+                             0 = chosen per launch from the number of workgroups; -1: env NST_H2_TILE_ROWS, default 0 */
 } nst_options;
 void nst_options_default(nst_options* opts);
 int nst_ctx_create_ex(int device, const float* const* weights, const float* const* biases, const nst_options* opts,
