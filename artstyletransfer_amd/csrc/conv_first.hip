@@ -15,7 +15,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
-constexpr int F_TH = 16, F_TW = 16;           // block tile: 16 x 16 pixels, 4 waves of 4 rows
+// Block tile: 16 x 16 pixels, 4 waves of 4 rows (two 32-pixel MFMA row tiles per wave).
+constexpr int F_TH = 16, F_TW = 16;
+constexpr int F_MT = F_TH / 8;                // 32-pixel row tiles per wave
 constexpr int F_PH = F_TH + 2, F_PW = F_TW + 2;
 constexpr int F_PLANE = F_PH * F_PW;
 
@@ -25,30 +27,52 @@ __host__ __device__ constexpr int tap_off(int k) {
 }
 }  // namespace
 
-__global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restrict__ x, int H, int W,
+// A PERSISTENT tile loop (grid = two workgroups per CU): per tile the kernel is a 64-KB store stream behind 1.7 us of
+// fp32 MFMA per wave, with a set-up in front - 28 weight loads per lane and the 3-plane halo patch - that a
+// one-tile-per-workgroup launch pays 6144 times at level 0 with nothing to hide it under (2.6 TB/s written, where a
+// plain fill reaches 6.9; 8-row tiles for twice the occupancy made it SLOWER: twice the set-up per pixel).  Here the
+// weights are loaded once per workgroup and the next tile's patch is fetched into registers before the current
+// tile's MFMAs and written to LDS after its stores.
+constexpr int F_PATCH_PER_T = (3 * F_PLANE + 255) / 256;
+
+__global__ __launch_bounds__(256, 2) void conv1_1_fwd_kernel(const float* __restrict__ x, int H, int W,
                                                           const float* __restrict__ wk,
                                                           const float* __restrict__ bias, float* __restrict__ out,
                                                           unsigned* __restrict__ bits_out,
-                                                          unsigned* __restrict__ amax_out) {
+                                                          unsigned* __restrict__ amax_out, int ntiles) {
     __shared__ float patch[3 * F_PLANE];
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int tiles_x = (W + F_TW - 1) / F_TW;
-    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x % tiles_x;
-    const int y0 = ty * F_TH, x0 = tx * F_TW;
 
-    for (int u = tid; u < 3 * F_PLANE; u += 256) {
-        const int c = u / F_PLANE;
-        const int r = (u % F_PLANE) / F_PW;
-        const int col = u % F_PW;
-        const int gy = y0 - 1 + r, gx = x0 - 1 + col;
-        float v = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = x[((size_t)c * H + gy) * W + gx];
-        patch[u] = v;
+    // patch element u of this thread: plane c, patch row r, patch column col (fixed for every tile)
+    int pu_off[F_PATCH_PER_T];          // (c, r, col) packed
+#pragma unroll
+    for (int i = 0; i < F_PATCH_PER_T; ++i) {
+        const int u = tid + i * 256;
+        const int c = u / F_PLANE, r = (u % F_PLANE) / F_PW, col = u % F_PW;
+        pu_off[i] = (u < 3 * F_PLANE) ? (c << 16) | (r << 8) | col : -1;
     }
+    auto fetch = [&](int tile, float* v) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y0 = ty * F_TH, x0 = tx * F_TW;
+#pragma unroll
+        for (int i = 0; i < F_PATCH_PER_T; ++i) {
+            const int pk = pu_off[i];
+            const int c = pk >> 16, gy = y0 - 1 + ((pk >> 8) & 255), gx = x0 - 1 + (pk & 255);
+            v[i] = (pk >= 0 && tile < ntiles && gy >= 0 && gy < H && gx >= 0 && gx < W) ? x[((size_t)c * H + gy) * W + gx] : 0.f;
+        }
+    };
+    auto stash = [&](const float* v) {
+#pragma unroll
+        for (int i = 0; i < F_PATCH_PER_T; ++i)
+            if (pu_off[i] >= 0) patch[tid + i * 256] = v[i];
+    };
 
-    // B operand: lane (n = l31, k-half) holds W[k = 2*kk + half][nt*32 + n]
+    float pv[F_PATCH_PER_T];
+    fetch(blockIdx.x, pv);
+    // B operand: lane (n = l31, k-half) holds W[k = 2*kk + half][nt*32 + n] - once per workgroup
     float bw[14][2];
 #pragma unroll
     for (int kk = 0; kk < 14; ++kk) {
@@ -56,81 +80,96 @@ __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restric
         bw[kk][0] = wk[k * 64 + l31];
         bw[kk][1] = wk[k * 64 + 32 + l31];
     }
+    const float bv0 = bias[l31], bv1 = bias[32 + l31];
+    stash(pv);
     __syncthreads();
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int prow = wave * 4 + (l31 >> 4);
+    constexpr int WROWS = 2 * F_MT;                 // image rows per wave
+    const int prow = wave * WROWS + (l31 >> 4);
     const int pcol = l31 & 15;
-    const int base0 = prow * F_PW + pcol;           // M-tile 0: rows wave*4 + {0,1}
-    const int base1 = (prow + 2) * F_PW + pcol;     // M-tile 1: rows wave*4 + {2,3}
-#pragma unroll
-    for (int kk = 0; kk < 14; ++kk) {
-        const int off = half ? tap_off(2 * kk + 1) : tap_off(2 * kk);
-        const float a0 = patch[base0 + off];
-        const float a1 = patch[base1 + off];
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bw[kk][0], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bw[kk][1], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw[kk][0], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bw[kk][1], acc[1][1], 0, 0, 0);
-    }
-
+    const int base0 = prow * F_PW + pcol;           // M-tile mt: rows wave * WROWS + 2 mt + {0,1}
     float amax = 0.f;
-    if (y0 + F_TH <= H && x0 + F_TW <= W && (size_t)H * W * 256 < 0xFFFFFF00ull) {
-        // interior tile: buffer stores = per-lane byte offset + a scalar offset per element, no bounds tests
-        // (the same form as conv_h2.hip's fast epilogue)
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, (unsigned)((size_t)H * W * 256), 0x00020000);
-        const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(bits_out, 0, bits_out ? (unsigned)((size_t)H * W * 8) : 0u, 0x00020000);
-        const int pix0 = (y0 + wave * 4) * W + x0 + 4 * half;
-        const unsigned vbase = (unsigned)(pix0 * 256 + l31 * 4);
-        const unsigned wlane = (l31 == 0) ? (unsigned)(pix0 * 8) : 0xFFFFFF00u;
+    const bool small = (size_t)H * W * 256 < 0xFFFFFF00ull;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out, 0, small ? (unsigned)((size_t)H * W * 256) : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(bits_out, 0, (bits_out && small) ? (unsigned)((size_t)H * W * 8) : 0u, 0x00020000);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+        const int y0 = ty * F_TH, x0 = tx * F_TW;
+        fetch(tile + gridDim.x, pv);                // the next tile's patch: in flight under this tile's MFMAs
+
+        f32x16 acc[F_MT][2];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const float bv = bias[nt * 32 + l31];
+        for (int a = 0; a < F_MT; ++a)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int poff = ((r >> 3) + 2 * mt) * W + (r & 3) + 8 * ((r >> 2) & 1);      // pixel offset (scalar)
-                    const float v = fmaxf(acc[mt][nt][r] + bv, 0.f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, vbase, poff * 256 + nt * 128, 0);
-                    amax = fmaxf(amax, v);
-                    if (bits_out) {
-                        const unsigned long long bal = __ballot(v > 0.f);
-                        __builtin_amdgcn_raw_buffer_store_b32(half ? (unsigned)(bal >> 32) : (unsigned)bal, rs_bits, wlane, poff * 8 + nt * 4, 0);
-                    }
-                }
-        }
-    } else {
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int co = nt * 32 + l31;
-        const float bv = bias[co];
+        for (int kk = 0; kk < 14; ++kk) {
+            const int off = half ? tap_off(2 * kk + 1) : tap_off(2 * kk);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int y = y0 + wave * 4 + mt * 2 + (m >> 4);
-                const int xx = x0 + (m & 15);
-                const bool inb = (y < H && xx < W);
-                const float v = fmaxf(acc[mt][nt][r] + bv, 0.f);
-                if (inb) {
-                    out[((size_t)y * W + xx) * 64 + co] = v;
-                    amax = fmaxf(amax, v);
-                }
-                if (bits_out) {
-                    const unsigned long long bal = __ballot(v > 0.f);
-                    if (l31 == 0 && inb) bits_out[((size_t)y * W + xx) * 2 + nt] = half ? (unsigned)(bal >> 32) : (unsigned)bal;
-                }
+            for (int mt = 0; mt < F_MT; ++mt) {
+                const float a = patch[base0 + 2 * mt * F_PW + off];
+                acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[kk][0], acc[mt][0], 0, 0, 0);
+                acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bw[kk][1], acc[mt][1], 0, 0, 0);
             }
-    }
+        }
+
+        if (y0 + F_TH <= H && x0 + F_TW <= W && small) {
+            // interior tile: buffer stores = per-lane byte offset + a scalar offset per element, no bounds tests
+            // (the same form as conv_h2.hip's fast epilogue)
+            const int pix0 = (y0 + wave * WROWS) * W + x0 + 4 * half;
+            const unsigned vbase = (unsigned)(pix0 * 256 + l31 * 4);
+            const unsigned wlane = (l31 == 0) ? (unsigned)(pix0 * 8) : 0xFFFFF000u;     // (+ immediates below 4 KiB: still beyond the buffer)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const float bv = nt ? bv1 : bv0;
+#pragma unroll
+                for (int mt = 0; mt < F_MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // pixel of register r: row (r >> 3) + 2 mt (a scalar offset, four values in all), column
+                        // (r & 3) + 8 ((r >> 2) & 1) (a compile-time constant: the instruction's immediate offset)
+                        const int rowpix = ((r >> 3) + 2 * mt) * W;
+                        const int colpix = (r & 3) + 8 * ((r >> 2) & 1);
+                        const float v = fmaxf(acc[mt][nt][r] + bv, 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, vbase + (unsigned)(colpix * 256 + nt * 128), rowpix * 256, 0);
+                        amax = fmaxf(amax, v);
+                        if (bits_out) {
+                            const unsigned long long bal = __ballot(v > 0.f);
+                            __builtin_amdgcn_raw_buffer_store_b32(half ? (unsigned)(bal >> 32) : (unsigned)bal, rs_bits, wlane + (unsigned)(colpix * 8 + nt * 4), rowpix * 8, 0);
+                        }
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int co = nt * 32 + l31;
+                const float bv = nt ? bv1 : bv0;
+#pragma unroll
+                for (int mt = 0; mt < F_MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int y = y0 + wave * WROWS + mt * 2 + (m >> 4);
+                        const int xx = x0 + (m & 15);
+                        const bool inb = (y < H && xx < W);
+                        const float v = fmaxf(acc[mt][nt][r] + bv, 0.f);
+                        if (inb) {
+                            out[((size_t)y * W + xx) * 64 + co] = v;
+                            amax = fmaxf(amax, v);
+                        }
+                        if (bits_out) {
+                            const unsigned long long bal = __ballot(v > 0.f);
+                            if (l31 == 0 && inb) bits_out[((size_t)y * W + xx) * 2 + nt] = half ? (unsigned)(bal >> 32) : (unsigned)bal;
+                        }
+                    }
+            }
+        }
+        __syncthreads();                    // every wave has read this tile's patch
+        stash(pv);
+        __syncthreads();
     }
     if (amax_out) {
         // absmax of the output for the fp16-piece convolution that consumes it (conv_h2.hip)
@@ -142,8 +181,9 @@ __global__ __launch_bounds__(256) void conv1_1_fwd_kernel(const float* __restric
 
 hipError_t launch_conv1_1_fwd(const float* x, int H, int W, const float* wk, const float* bias, float* out,
                               unsigned* bits_out, unsigned* amax_out, hipStream_t stream) {
-    const int blocks = ((H + F_TH - 1) / F_TH) * ((W + F_TW - 1) / F_TW);
-    hipLaunchKernelGGL(conv1_1_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, H, W, wk, bias, out, bits_out, amax_out);
+    const int ntiles = ((H + F_TH - 1) / F_TH) * ((W + F_TW - 1) / F_TW);
+    const int blocks = ntiles < 512 ? ntiles : 512;          // two workgroups per CU, each walking tiles b, b + 512, ...
+    hipLaunchKernelGGL(conv1_1_fwd_kernel, dim3(blocks), dim3(256), 0, stream, x, H, W, wk, bias, out, bits_out, amax_out, ntiles);
     return hipGetLastError();
 }
 

@@ -54,7 +54,10 @@ struct ConvParams {
 constexpr int NST_AMAX_SLOTS = 64;
 // conv_h2: launches with at most this many input channels (K <= 1152) use the 16-channel-chunk shapes, and the
 // host lays their pre-cut weights out in 16-channel chunks (make_h2)
-constexpr int NST_H2_SHORTK_CIN = 128;
+#ifndef NST_H2_SHORTK_CIN_VALUE
+#define NST_H2_SHORTK_CIN_VALUE 128
+#endif
+constexpr int NST_H2_SHORTK_CIN = NST_H2_SHORTK_CIN_VALUE;      // (-DNST_H2_SHORTK_CIN_VALUE=512: experiment builds)
 
 // One image (pyramid level) of a batched conv_bf3 launch; the layer's weights / channel counts are shared.
 struct ConvImage {
