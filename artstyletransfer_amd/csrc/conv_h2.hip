@@ -40,6 +40,9 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 namespace {
 
+#ifndef NST_H2_DEEP_WEIGHT_PREFETCH
+#define NST_H2_DEEP_WEIGHT_PREFETCH 1
+#endif
 constexpr float LO_UP = 2048.f;   // 2^11
 constexpr float LO_DOWN = 1.f / 2048.f;
 
@@ -153,6 +156,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
 
     f32x4 ra[C::A_PER_T];
     u32x4 rb[C::B_PER_T];
+    // (KC == 16 shapes: a second weight staging set, see the main K loop)
+    constexpr bool DEEPB = (KC == 16) && NST_H2_DEEP_WEIGHT_PREFETCH;
+    u32x4 rb2[DEEPB ? C::B_PER_T : 1];
 
     // Staging unit i of this lane: u = tid + i * NT; patch unit = (pixel u >> 3, channel quad u & 7), weight unit =
     // (row u >> 3, 16-byte piece u & 7).  Addresses are recomputed where they are used, from a thread id the compiler
@@ -499,6 +505,7 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             load_b(r0, 0, 0, tid);
             load_b(r1, 0, 1, tid);
             load_b(rb, 0, 2, tid);
+            if constexpr (DEEPB) load_b(rb2, 0, 3, tid);
             __syncthreads();          // the previous source is done with the LDS buffers
             store_a(ldsA, sa, ra, 0, C::A_PER_T, tid, UNPOOL ? rc : nullptr, bit0_of(0));
             store_b(ldsB, r0, tid);
@@ -532,9 +539,25 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 // top of stage g = 9 c + t: slice g+2 to LDS, slice g+3 on its way
-                store_b(ldsB + ((t + 2) % 3) * C::B_BYTES, rb, to);
-                if (t + 3 < 9) load_b(rb, c, t + 3, to);
-                else load_b(rb, cn, t + 3 - 9, to);
+                if constexpr (DEEPB) {
+                    // 16-channel chunks: a stage is 12 MFMAs (~400 cycles, ~800 with the other workgroup's wave on the SIMD) -
+                    // shorter than an L2 round trip, so a slice loaded ONE stage ahead arrives late and every stage
+                    // waits for it.  Two register sets alternate: slice g+2 goes to LDS from the set loaded two stages
+                    // ago, and that set is re-loaded with slice g+4.
+                    if (((PAR + t) & 1) == 0) {
+                        store_b(ldsB + ((t + 2) % 3) * C::B_BYTES, rb, to);
+                        if (t + 4 < 9) load_b(rb, c, t + 4, to);
+                        else load_b(rb, cn, t + 4 - 9, to);
+                    } else {
+                        store_b(ldsB + ((t + 2) % 3) * C::B_BYTES, rb2, to);
+                        if (t + 4 < 9) load_b(rb2, c, t + 4, to);
+                        else load_b(rb2, cn, t + 4 - 9, to);
+                    }
+                } else {
+                    store_b(ldsB + ((t + 2) % 3) * C::B_BYTES, rb, to);
+                    if (t + 3 < 9) load_b(rb, c, t + 3, to);
+                    else load_b(rb, cn, t + 3 - 9, to);
+                }
                 if (t == 0) load_a(ra, cn, 0, AH, to);
                 if (t == 4) load_a(ra, cn, AH, C::A_PER_T, to);
                 // keep the loads HERE: left free, the scheduler sinks them towards the end of the stage (their

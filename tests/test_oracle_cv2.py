@@ -83,11 +83,14 @@ def test_host_mirror_vs_oracle():
     from artstyletransfer_amd import config, host_image as hi
     rs = np.random.RandomState(5)
     img = rs.rand(37, 53, 3).astype(np.float32)
-    # fp32 implementations (torch's kernel here, OpenCV's own float path, the device kernel) form the source coordinate
-    # (d + 0.5) * scale - 0.5 in fp32: its rounding (one ulp of a coordinate ~50 is 4e-6) moves the taps' weights by a few
-    # 1e-6 - measured 3.7e-6 on a 37x53 -> 18x26 shrink; the oracle works in double
+    # fp32 implementations (torch's kernel here, OpenCV's own float path, the device kernel) hold the source coordinate
+    # (d + 0.5) * scale - 0.5 in fp32: its rounding - half an ulp of a coordinate f, i.e. 6e-8 f, twice where the
+    # coordinate is also FORMED in fp32 as torch does - moves the four weights by as much and the result by up to that
+    # times the pixel contrast (white noise here): measured 3.7e-6 on a 37x53 -> 18x26 shrink, 1.9e-5 on 150x200 -> 256x341.
+    # The oracle works in double.
+    tol = lambda h, w: 2 * (2e-6 + 1.5e-7 * max(h, w))
     for nh, nw in ((74, 106), (18, 26), (256, 367), (9, 13)):
-        np.testing.assert_allclose(hi.bicubic_resize(img, nh, nw), cv2_ref.resize_cubic(img, nh, nw), atol=6e-6)
+        np.testing.assert_allclose(hi.bicubic_resize(img, nh, nw), cv2_ref.resize_cubic(img, nh, nw), atol=tol(37, 53))
     for args in ((2875, 4312, 0), (2875, 4312, 2), (391, 470, 0), (500, 500, 1), (300, 200, 0)):
         assert hi.level_size(*args) == cv2_ref.level_size(*args)
     np.testing.assert_allclose(hi.sobel5(img, 1, 0), cv2_ref.sobel5(img, 1, 0), atol=1e-12)
@@ -100,7 +103,7 @@ def test_host_mirror_vs_oracle():
     content = rs.rand(150, 200, 3).astype(np.float32)
     style = rs.rand(90, 140, 3).astype(np.float32)
     ct, st = hi.resize_to_level(content, 0), hi.resize_to_level(style, 0)
-    np.testing.assert_allclose(ct, cv2_ref.resize_cubic(content, *cv2_ref.level_size(150, 200, 0)), atol=6e-6)
+    np.testing.assert_allclose(ct, cv2_ref.resize_cubic(content, *cv2_ref.level_size(150, 200, 0)), atol=tol(150, 200))
     args = (cfg.noise_factor, cfg.noise_levels, cfg.noise_levels_central_amplitude, cfg.noise_levels_peripheral_amplitude,
             cfg.noise_levels_dispersion)
     for method in ("content+noise", "random", "style"):
@@ -109,10 +112,10 @@ def test_host_mirror_vs_oracle():
         np.random.seed(11)
         b, tb = cv2_ref.initial_image(method, content, style, ct, st, 0, *args)
         assert ta == tb and a.shape == b.shape
-        np.testing.assert_allclose(a, b, atol=1e-5)
+        np.testing.assert_allclose(a, b, atol=tol(256, 341))
     # tall image: the other branch of the grid-size rule; a negative granularity
     np.random.seed(3)
     a = hi.noise_map(style, (96, 64, 3), (5, -2, 0), (0.3, 0.2, 0.2), (0.2, 0.1, 0.0), (0.2, 0.6, 0.3))
     np.random.seed(3)
     b = cv2_ref.noise_map(style, (96, 64, 3), (5, -2, 0), (0.3, 0.2, 0.2), (0.2, 0.1, 0.0), (0.2, 0.6, 0.3))
-    np.testing.assert_allclose(a, b, atol=1e-5)
+    np.testing.assert_allclose(a, b, atol=tol(96, 64))
