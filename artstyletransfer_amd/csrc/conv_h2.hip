@@ -43,6 +43,16 @@ namespace {
 #ifndef NST_H2_DEEP_WEIGHT_PREFETCH
 #define NST_H2_DEEP_WEIGHT_PREFETCH 1
 #endif
+// Timing-only builds (tools/ablate_conv.sh; never shipped): a set bit gives one stream of the kernel a buffer descriptor
+// with zero records, so the range check drops its loads / stores while the instruction stream, the waits and the
+// barriers stay - the launch then shows what that stream's memory traffic costs.  bit 0: the patch loads of the main
+// source, 1: its weight loads, 2: the stores of the fast epilogues, 3: their loads (mask words, addend), 4: the loads of
+// the second (Gram) source.
+#ifndef NST_H2_ABLATE
+#define NST_H2_ABLATE 0
+#endif
+constexpr unsigned ABL_IN = (NST_H2_ABLATE & 1) ? 0u : 1u, ABL_W = (NST_H2_ABLATE & 2) ? 0u : 1u, ABL_ST = (NST_H2_ABLATE & 4) ? 0u : 1u,
+                   ABL_EL = (NST_H2_ABLATE & 8) ? 0u : 1u, ABL_G = (NST_H2_ABLATE & 16) ? 0u : 1u;
 constexpr float LO_UP = 2048.f;   // 2^11
 constexpr float LO_DOWN = 1.f / 2048.f;
 
@@ -128,8 +138,17 @@ __device__ __forceinline__ void cut2x4(const f32x4 v, const float s, u32x2& hi, 
 // power/clock bound: tools/micro/mfma_power.hip measures +7 % with this kernel's fragment traffic).  Staging and LDS
 // layout are shared; the fragment addressing, the MFMA order and the epilogues (accumulator layout: a lane holds 4
 // consecutive pixels of one channel instead of 16 pixel-rows of one channel) have a form of their own.
-template <int TH, int BN, int NTW, int KC, bool UNPOOL, bool M16>
-__device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, const int ct, const int slot_seed) {
+//
+// `tiles` deals this workgroup its tiles: tiles.get(k, p, sp, ct) fills the launch parameters, the spatial tile and the
+// output-channel tile of the k-th one (false: there is none).  A workgroup of a PERSISTENT launch (nst_options.h2_persist)
+// walks several, and the software pipeline of the K loop then runs ACROSS them: the look-ahead of a tile's last chunk
+// stages the first chunk of the NEXT tile (its patch, the weight slices of its first stages) instead of a dummy, so the
+// next tile starts without a prologue - no load latency, no LDS staging - right behind this tile's epilogue, whose stores
+// drain under its first stages.  Per tile of a one-tile-per-workgroup launch that prologue + dispatch + the write burst
+// of 256 CUs finishing in lock-step cost ~11 us (fit over the 72- and 144-stage layers), 6 - 11 % of a launch.
+// The arithmetic of a tile does not depend on how it was reached: both launch forms give bitwise the same tensors.
+template <int TH, int BN, int NTW, int KC, bool UNPOOL, bool M16, class Tiles>
+__device__ __forceinline__ void conv_h2_body(const Tiles& tiles, const int slot_seed) {
     static_assert(!M16 || KC == 32, "the 16x16x32 form takes a whole 32-channel chunk per MFMA");
     using C = H2Cfg<TH, BN, NTW, KC>;
     constexpr int ROWB = C::ROWB, WROWB = C::WROWB, QP = C::QP, PIECEB = C::PIECEB, KS = C::KS;
@@ -147,18 +166,41 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     const int half = lane >> 5;
     const int l31 = lane & 31;
 
+    // weight staging registers: they carry the slices of a chained tile's stages 2 (and 3) from one tile to the next
+    u32x4 rb[C::B_PER_T];
+    // (KC == 16 shapes: a second weight staging set, see the main K loop)
+    constexpr bool DEEPB = (KC == 16) && NST_H2_DEEP_WEIGHT_PREFETCH;
+    u32x4 rb2[DEEPB ? C::B_PER_T : 1];
+
+    ConvParams p;
+    int sp = 0, ct = 0;
+    (void)tiles.get(0, p, sp, ct);
+    bool primed = false;         // the first chunk of this tile is in LDS already (staged under the previous tile)
+  for (int tile_k = 0;; ++tile_k) {
     const int ty_rel = sp / p.tiles_x;
     const int tx = sp - ty_rel * p.tiles_x;
     const int ty = ty_rel + p.ty0;
     const int y0 = ty * TH;
     const int x0 = tx * C::TW;
     const int n0 = ct * BN;
+    // The next tile of this workgroup: here only whether the pipeline chains into it and its operand scale; what else
+    // the look-ahead needs is fetched in the last chunk, and the epilogue fetches its own copy of this tile's parameters
+    // (kernel arguments, re-read through an index the compiler cannot see through) - three sets of tensor pointers alive
+    // over the K loop would not fit the scalar registers.
+    auto opaque_s = [](int v) { asm volatile("" : "+s"(v)); return v; };
+    float nx_sa = 1.f;
+    bool chain = false;
+    {
+        ConvParams pn;
+        int spn = 0, ctn = 0;
+        if (tiles.get(tile_k + 1, pn, spn, ctn) && p.Cin > 0 && !p.in2 && !pn.in2) {
+            chain = true;
+            float unused_inv;
+            tensor_scale(pn.amax_in, lane, nx_sa, unused_inv);
+        }
+    }
 
     f32x4 ra[C::A_PER_T];
-    u32x4 rb[C::B_PER_T];
-    // (KC == 16 shapes: a second weight staging set, see the main K loop)
-    constexpr bool DEEPB = (KC == 16) && NST_H2_DEEP_WEIGHT_PREFETCH;
-    u32x4 rb2[DEEPB ? C::B_PER_T : 1];
 
     // Staging unit i of this lane: u = tid + i * NT; patch unit = (pixel u >> 3, channel quad u & 7), weight unit =
     // (row u >> 3, 16-byte piece u & 7).  Addresses are recomputed where they are used, from a thread id the compiler
@@ -173,30 +215,31 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     };
     // byte offset of patch unit i inside the image tensor; outside the image / unused: beyond the buffer (reads 0).
     // `pooled`: the tensor is the 2x2-pooled map (H/2 x W/2) and pixel (gy, gx) reads its window's element.
-    auto a_voff_of = [&](int i, int to, int cin, const bool pooled) -> unsigned {
+    // (gH, gW, gy0, gx0: image size and tile origin - this tile's, or the next one's for the look-ahead of the last chunk)
+    auto a_voff_of = [&](int i, int to, int cin, const bool pooled, const int gH, const int gW, const int gy0, const int gx0) -> unsigned {
         const int u = to + i * C::NT;
         const int pix = u / QP;
         const int pr = pix / C::PW;
         const int pc = pix - pr * C::PW;
-        const int gy = y0 - 1 + pr;
-        const int gx = x0 - 1 + pc;
+        const int gy = gy0 - 1 + pr;
+        const int gx = gx0 - 1 + pc;
         // (unsigned compares fold the >= 0 tests; bitwise & keeps this a select instead of short-circuit branches)
-        bool ok = (u < C::A_UNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
-        if (!pooled) return ok ? ((unsigned)(gy * p.W + gx) * (unsigned)cin + (unsigned)(u % QP) * 4u) * 4u : 0xFFFFFF00u;
-        const int PH2 = p.H >> 1, PW2 = p.W >> 1;
+        bool ok = (u < C::A_UNITS) & ((unsigned)gy < (unsigned)gH) & ((unsigned)gx < (unsigned)gW);
+        if (!pooled) return ok ? ((unsigned)(gy * gW + gx) * (unsigned)cin + (unsigned)(u % QP) * 4u) * 4u : 0xFFFFFF00u;
+        const int PH2 = gH >> 1, PW2 = gW >> 1;
         ok = ok & ((gy >> 1) < PH2) & ((gx >> 1) < PW2);      // the odd last row / column belongs to no window
         return ok ? ((unsigned)((gy >> 1) * PW2 + (gx >> 1)) * (unsigned)cin + (unsigned)(u % QP) * 4u) * 4u : 0xFFFFFF00u;
     };
     // byte offset of the arg-max code word of patch unit i: [pooled pixel][32-channel group][window position]
-    auto a_coff_of = [&](int i, int to, int cin) -> unsigned {
+    auto a_coff_of = [&](int i, int to, int cin, const int gH, const int gW, const int gy0, const int gx0) -> unsigned {
         const int u = to + i * C::NT;
         const int pix = u / QP;
         const int pr = pix / C::PW;
         const int pc = pix - pr * C::PW;
-        const int gy = y0 - 1 + pr;
-        const int gx = x0 - 1 + pc;
-        const int PH2 = p.H >> 1, PW2 = p.W >> 1;
-        const bool ok = (u < C::A_UNITS) & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W) &
+        const int gy = gy0 - 1 + pr;
+        const int gx = gx0 - 1 + pc;
+        const int PH2 = gH >> 1, PW2 = gW >> 1;
+        const bool ok = (u < C::A_UNITS) & ((unsigned)gy < (unsigned)gH) & ((unsigned)gx < (unsigned)gW) &
                         ((gy >> 1) < PH2) & ((gx >> 1) < PW2);
         return ok ? (((unsigned)((gy >> 1) * PW2 + (gx >> 1)) * (unsigned)(cin >> 5)) * 4u + (unsigned)((gy & 1) * 2 + (gx & 1))) * 4u : 0xFFFFFF00u;
     };
@@ -379,9 +422,9 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     auto gram_source = [&](const float* src, const int cin, const float* wts, const float sa, const float sw) {
         const int nch = cin / KC;
         const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(src), 0, (unsigned)((size_t)p.H * p.W * cin * 4), 0x00020000);
+            const_cast<float*>(src), 0, (unsigned)((size_t)p.H * p.W * cin * 4) * ABL_G, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(wts), 0, (unsigned)((size_t)p.Cout * cin * 4), 0x00020000);
+            const_cast<float*>(wts), 0, (unsigned)((size_t)p.Cout * cin * 4) * ABL_G, 0x00020000);
         // A 1-tap source reads the centre of the patch only: stage just the TH x 16 output pixels (no halo ring,
         // no division by the patch width) - the Gram stages are bound by this staging, not by their MFMAs.
         constexpr int G_PER_T = TH * C::TW * QP / C::NT;
@@ -469,26 +512,41 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         const int nch = cin / KC;
         const size_t in_px = UNPOOL ? (size_t)(p.H >> 1) * (p.W >> 1) : (size_t)p.H * p.W;
         const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(src), 0, (unsigned)(in_px * cin * 4), 0x00020000);
+            const_cast<float*>(src), 0, (unsigned)(in_px * cin * 4) * ABL_IN, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<void*>(wts), 0, (unsigned)((size_t)9 * p.Cout * nch * WROWB), 0x00020000);
+            const_cast<void*>(wts), 0, (unsigned)((size_t)9 * p.Cout * nch * WROWB) * ABL_W, 0x00020000);
         const __amdgpu_buffer_rsrc_t rsrc_code = __builtin_amdgcn_make_buffer_rsrc(
             const_cast<unsigned*>(UNPOOL ? p.pcode_in : nullptr), 0, UNPOOL ? (unsigned)(in_px * (cin >> 5) * 16) : 0u, 0x00020000);
+        // where a chunk's patch comes from: this tile, or (look-ahead of the last chunk of a chained tile) the next one
+        struct Look { __amdgpu_buffer_rsrc_t rs_in, rs_code; int H, W, y0, x0, n0; float sa; };
+        const Look here{rsrc_in, rsrc_code, p.H, p.W, y0, x0, n0, sa};
+        auto there = [&]() -> Look {
+            ConvParams pn;
+            int spn = 0, ctn = 0;
+            (void)tiles.get(opaque_s(tile_k + 1), pn, spn, ctn);
+            const size_t px = UNPOOL ? (size_t)(pn.H >> 1) * (pn.W >> 1) : (size_t)pn.H * pn.W;
+            const int tyn = spn / pn.tiles_x;
+            return Look{__builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pn.in), 0, (unsigned)(px * cin * 4), 0x00020000),
+                        __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(UNPOOL ? pn.pcode_in : nullptr), 0,
+                                                          UNPOOL ? (unsigned)(px * (cin >> 5) * 16) : 0u, 0x00020000),
+                        pn.H, pn.W, (tyn + pn.ty0) * TH, (spn - tyn * pn.tiles_x) * C::TW, ctn * BN, nx_sa};
+        };
         unsigned rc[UNPOOL ? C::A_PER_T : 1];
         // patch units [i0, i1) of a chunk -> r[0 .. i1-i0) (+ their arg-max code words when un-pooling)
-        auto load_a = [&](f32x4* r, int chunk, const int i0, const int i1, const int to) {
+        auto load_a = [&](f32x4* r, const Look& k, int chunk, const int i0, const int i1, const int to) {
 #pragma unroll
             for (int i = i0; i < i1; ++i) {
-                r[i - i0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, a_voff_of(i, to, cin, UNPOOL), chunk * KC * 4, 0));
+                r[i - i0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                          k.rs_in, a_voff_of(i, to, cin, UNPOOL, k.H, k.W, k.y0, k.x0), chunk * KC * 4, 0));
                 if (UNPOOL)
-                    rc[i - i0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_code, a_coff_of(i, to, cin), ((chunk * KC) >> 5) * 16, 0);
+                    rc[i - i0] = __builtin_amdgcn_raw_buffer_load_b32(k.rs_code, a_coff_of(i, to, cin, k.H, k.W, k.y0, k.x0), ((chunk * KC) >> 5) * 16, 0);
             }
         };
         // first code bit of a chunk inside its 32-channel word
         auto bit0_of = [&](int chunk) { return (chunk * KC) & 31; };
         // pre-cut weights: [tap][Cout][chunk][piece][32] fp16, i.e. 128 contiguous bytes per (tap, cout, chunk)
-        auto load_b = [&](u32x4 (&r)[C::B_PER_T], int chunk, int tap, const int to) {
-            const int soff = ((tap * p.Cout + n0) * nch + chunk) * WROWB;
+        auto load_b = [&](u32x4 (&r)[C::B_PER_T], int chunk, int tap, const int to, const int cout0) {
+            const int soff = ((tap * p.Cout + cout0) * nch + chunk) * WROWB;
 #pragma unroll
             for (int i = 0; i < C::B_PER_T; ++i) {
                 const int u = to + i * C::NT;
@@ -498,20 +556,21 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         };
         auto tap_off = [](int t) { return (t / 3) * C::PROWB + (t % 3) * ROWB; };
 
-        // prologue: chunk 0 and the slices of stages 0, 1 into LDS, slice 2 into registers
-        {
+        // prologue: chunk 0 and the slices of stages 0, 1 into LDS, slice 2 into registers - unless the previous tile of
+        // this workgroup left exactly that state behind (`primed`)
+        if (!primed) {
             u32x4 r0[C::B_PER_T], r1[C::B_PER_T];
-            load_a(ra, 0, 0, C::A_PER_T, tid);
-            load_b(r0, 0, 0, tid);
-            load_b(r1, 0, 1, tid);
-            load_b(rb, 0, 2, tid);
-            if constexpr (DEEPB) load_b(rb2, 0, 3, tid);
+            load_a(ra, here, 0, 0, C::A_PER_T, tid);
+            load_b(r0, 0, 0, tid, n0);
+            load_b(r1, 0, 1, tid, n0);
+            load_b(rb, 0, 2, tid, n0);
+            if constexpr (DEEPB) load_b(rb2, 0, 3, tid, n0);
             __syncthreads();          // the previous source is done with the LDS buffers
             store_a(ldsA, sa, ra, 0, C::A_PER_T, tid, UNPOOL ? rc : nullptr, bit0_of(0));
             store_b(ldsB, r0, tid);
             store_b(ldsB + C::B_BYTES, r1, tid);
+            __syncthreads();
         }
-        __syncthreads();
         if constexpr (M16) {
             read_a(RA[0], ldsA + tap_off(0), 0);
             read_b(RB[0], ldsB, 0);
@@ -532,8 +591,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             unsigned char* anext = ldsA + ((c + 1) & 1) * C::A_BYTES;
             // The stage body is branch-free so that the compiler's s_waitcnt counts stay exact (a vmcnt merged over
             // control flow waits for ALL loads, i.e. for the patch loads from HBM issued one stage earlier).  In the
-            // last chunk the look-ahead re-loads valid addresses (chunk cn) into buffers nobody reads any more.
-            const int cn = (c + 1 < nch) ? c + 1 : c;
+            // last chunk the look-ahead stages chunk 0 of the workgroup's next tile (`there`), or - there is none, or
+            // one of the two has a second source - re-loads valid addresses (chunk cn) into buffers nobody reads any more.
+            const bool last = (c + 1 >= nch);
+            const int cn = last ? (chain ? 0 : c) : c + 1;
+            Look ahead = here;
+            if (last && chain) ahead = there();
             const int to = opaque(tid);
             constexpr int AH = (C::A_PER_T + 1) / 2;      // the next patch is staged in two halves (registers)
 #pragma unroll
@@ -546,25 +609,25 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
                     // ago, and that set is re-loaded with slice g+4.
                     if (((PAR + t) & 1) == 0) {
                         store_b(ldsB + ((t + 2) % 3) * C::B_BYTES, rb, to);
-                        if (t + 4 < 9) load_b(rb, c, t + 4, to);
-                        else load_b(rb, cn, t + 4 - 9, to);
+                        if (t + 4 < 9) load_b(rb, c, t + 4, to, n0);
+                        else load_b(rb, cn, t + 4 - 9, to, ahead.n0);
                     } else {
                         store_b(ldsB + ((t + 2) % 3) * C::B_BYTES, rb2, to);
-                        if (t + 4 < 9) load_b(rb2, c, t + 4, to);
-                        else load_b(rb2, cn, t + 4 - 9, to);
+                        if (t + 4 < 9) load_b(rb2, c, t + 4, to, n0);
+                        else load_b(rb2, cn, t + 4 - 9, to, ahead.n0);
                     }
                 } else {
                     store_b(ldsB + ((t + 2) % 3) * C::B_BYTES, rb, to);
-                    if (t + 3 < 9) load_b(rb, c, t + 3, to);
-                    else load_b(rb, cn, t + 3 - 9, to);
+                    if (t + 3 < 9) load_b(rb, c, t + 3, to, n0);
+                    else load_b(rb, cn, t + 3 - 9, to, ahead.n0);
                 }
-                if (t == 0) load_a(ra, cn, 0, AH, to);
-                if (t == 4) load_a(ra, cn, AH, C::A_PER_T, to);
+                if (t == 0) load_a(ra, ahead, cn, 0, AH, to);
+                if (t == 4) load_a(ra, ahead, cn, AH, C::A_PER_T, to);
                 // keep the loads HERE: left free, the scheduler sinks them towards the end of the stage (their
                 // registers are then shared with the fragments) and the next stage stalls on them
                 __builtin_amdgcn_sched_barrier(0);
-                if (t == 3) store_a(anext, sa, ra, 0, AH, to, UNPOOL ? rc : nullptr, bit0_of(cn));
-                if (t == 7) store_a(anext, sa, ra, AH, C::A_PER_T, to, UNPOOL ? rc : nullptr, bit0_of(cn));
+                if (t == 3) store_a(anext, ahead.sa, ra, 0, AH, to, UNPOOL ? rc : nullptr, bit0_of(cn));
+                if (t == 7) store_a(anext, ahead.sa, ra, AH, C::A_PER_T, to, UNPOOL ? rc : nullptr, bit0_of(cn));
                 const unsigned char* bcur = ldsB + (t % 3) * C::B_BYTES;
                 const unsigned char* anxt = (t + 1 < 9) ? acur + tap_off(t + 1) : anext + tap_off(0);
                 const unsigned char* bnxt = ldsB + ((t + 1) % 3) * C::B_BYTES;
@@ -659,6 +722,14 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
     if (has_main) main_source(p.in, p.Cin, p.wt_h2, sa1);
 
     // epilogue: D[m][n]: n = lane&31, m = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    auto epilogue = [&, &p_loop = p]() {
+    // (this tile's parameters again, see the top of the tile loop; a launch over one image has them in its arguments)
+    ConvParams p;
+    {
+        int sp_again, ct_again;
+        if (Tiles::REFETCH) (void)tiles.get(opaque_s(tile_k), p, sp_again, ct_again);
+        else p = p_loop;
+    }
     const int words = p.Cout >> 5;          // ReLU bit-mask words per pixel
     float amax = 0.f;
     auto record_amax = [&]() {
@@ -690,10 +761,10 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             const int pix0 = (y0 + wm * 4) * p.W + x0 + 4 * kg;          // this lane's first pixel
             const unsigned vbase = (unsigned)pix0 * (unsigned)colB + (unsigned)(cg0 + l15) * 4u;
             const unsigned wbase = (unsigned)pix0 * (unsigned)wcolB + (unsigned)(cg0 >> 5) * 4u;
-            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes * ABL_ST, 0x00020000);
             if (bwd_like) {
-                const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.bits_in), 0, bit_bytes, 0x00020000);
-                const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.addend), 0, p.addend ? out_bytes : 0u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.bits_in), 0, bit_bytes * ABL_EL, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.addend), 0, p.addend ? out_bytes * ABL_EL : 0u, 0x00020000);
                 // all mask words of the tile first (the fragment registers are free now), then arithmetic and stores
                 unsigned wv[4][4][NTW];
 #pragma unroll
@@ -732,10 +803,10 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
             } else {
                 const int PW2 = p.W >> 1;
                 const unsigned pool_bytes = (unsigned)((size_t)(p.H >> 1) * PW2 * p.Cout * 4);
-                const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(p.bits_out, 0, p.bits_out ? bit_bytes : 0u, 0x00020000);
-                const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc(p.pool_out, 0, p.pool_out ? pool_bytes : 0u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(p.bits_out, 0, p.bits_out ? bit_bytes * ABL_ST : 0u, 0x00020000);
+                const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc(p.pool_out, 0, p.pool_out ? pool_bytes * ABL_ST : 0u, 0x00020000);
                 const __amdgpu_buffer_rsrc_t rs_code = __builtin_amdgcn_make_buffer_rsrc(
-                    p.pcode_out, 0, p.pcode_out ? (unsigned)((size_t)(p.H >> 1) * PW2 * words * 16) : 0u, 0x00020000);
+                    p.pcode_out, 0, p.pcode_out ? (unsigned)((size_t)(p.H >> 1) * PW2 * words * 16) * ABL_ST : 0u, 0x00020000);
                 // one lane per pixel column group writes the bit words; the others carry an offset beyond the buffer (dropped)
                 const unsigned wlane = (l15 == 0) ? wbase : 0xFFFFFF00u;
                 const int ppix0 = ((y0 + wm * 4) >> 1) * PW2 + ((x0 + 4 * kg) >> 1);
@@ -895,12 +966,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         const int cg0 = n0 + wn * 32 * NTW;                          // this wave's first output channel
         const unsigned vbase = (unsigned)pix0 * (unsigned)colB + (unsigned)(cg0 + l31) * 4u;      // (mod 2^32: tensors up to 4 GiB)
         const unsigned wbase = (unsigned)pix0 * (unsigned)wcolB + (unsigned)(cg0 >> 5) * 4u;
-        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(p.out, 0, out_bytes * ABL_ST, 0x00020000);
         // (mt, r) -> scalar offsets of the element's pixel: row (r >> 3) + 2 mt, column (r & 3) + 8 ((r >> 2) & 1)
         auto soff = [&](int mt, int r, int rb, int cb) { return ((r >> 3) + 2 * mt) * rb + ((r & 3) + 8 * ((r >> 2) & 1)) * cb; };
         if (bwd_like) {
-            const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.bits_in), 0, bit_bytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.addend), 0, p.addend ? out_bytes : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(p.bits_in), 0, bit_bytes * ABL_EL, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.addend), 0, p.addend ? out_bytes * ABL_EL : 0u, 0x00020000);
             const float lo_clamp = p.relu ? 0.f : -__builtin_inff();
             if (!p.addend) {
                 // No addend (every input-gradient launch but the one below the content layer): ALL mask words of the
@@ -972,10 +1043,10 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         } else {
             const int PW2 = p.W >> 1;
             const unsigned pool_bytes = (unsigned)((size_t)(p.H >> 1) * PW2 * p.Cout * 4);
-            const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(p.bits_out, 0, p.bits_out ? bit_bytes : 0u, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc(p.pool_out, 0, p.pool_out ? pool_bytes : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_bits = __builtin_amdgcn_make_buffer_rsrc(p.bits_out, 0, p.bits_out ? bit_bytes * ABL_ST : 0u, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc(p.pool_out, 0, p.pool_out ? pool_bytes * ABL_ST : 0u, 0x00020000);
             const __amdgpu_buffer_rsrc_t rs_code = __builtin_amdgcn_make_buffer_rsrc(
-                p.pcode_out, 0, p.pcode_out ? (unsigned)((size_t)(p.H >> 1) * PW2 * words * 16) : 0u, 0x00020000);
+                p.pcode_out, 0, p.pcode_out ? (unsigned)((size_t)(p.H >> 1) * PW2 * words * 16) * ABL_ST : 0u, 0x00020000);
             // one lane per half-wave writes the bit words; the others carry an offset beyond the buffer (dropped)
             const unsigned wlane = (l31 == 0) ? wbase : 0xFFFFFF00u;
             const int ppix0 = ((y0 + wm * 4) >> 1) * PW2 + ((x0 + 4 * half) >> 1);
@@ -1109,6 +1180,12 @@ __device__ __forceinline__ void conv_h2_body(const ConvParams& p, const int sp, 
         }
     }
     record_amax();
+    };
+    epilogue();
+    // on to the workgroup's next tile (a chained one finds its first chunk staged)
+    if (!tiles.get(tile_k + 1, p, sp, ct)) break;
+    primed = chain;
+  }
 }
 
 // Workgroups are dealt to the 8 XCDs round-robin (workgroup b runs on XCD b % 8) and every XCD has its own L2.  The
@@ -1125,34 +1202,70 @@ __device__ __forceinline__ int xcd_contiguous(const int b, const int grid) {
 #endif
 }
 
+// one image, one tile per workgroup
+struct H2OneTile {
+    static constexpr bool REFETCH = false;
+    const ConvParams& p;
+    int n_ct;
+    __device__ __forceinline__ bool get(const int k, ConvParams& q, int& sp, int& ct) const {
+        if (k > 0) return false;
+        const int t = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+        q = p;
+        sp = t / n_ct;
+        ct = t % n_ct;
+        return true;
+    }
+};
+// several images; one tile per workgroup, or (b.persist: the grid is a multiple of 8 that fills the chip once) the
+// workgroup's share of its XCD's contiguous range: the order in which a one-tile-per-workgroup grid would have met them
+template <bool PERSIST>
+struct H2BatchTiles {
+    static constexpr bool REFETCH = PERSIST;
+    const ConvBatch& b;
+    int n_ct;
+    __device__ __forceinline__ bool get(const int k, ConvParams& p, int& sp, int& ct) const {
+        int t;
+        if (!PERSIST) {
+            if (k > 0) return false;
+            t = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+        } else {
+            const int x = (int)blockIdx.x & 7, j = ((int)blockIdx.x >> 3) + k * ((int)gridDim.x >> 3);
+            const int q = b.total_tiles >> 3, r = b.total_tiles & 7;
+            if (j >= q + (x < r ? 1 : 0)) return false;
+            t = x * q + (x < r ? x : r) + j;
+        }
+        const int sp_all = t / n_ct;
+        ct = t - sp_all * n_ct;
+        int i = 0;
+        while (i + 1 < b.n && sp_all >= b.img[i].tile_end) ++i;
+        const ConvImage& im = b.img[i];
+        p.in = im.in; p.wt = nullptr; p.wt_bf = nullptr; p.bias = b.bias; p.addend = im.addend; p.mask = im.mask; p.out = im.out;
+        p.H = im.H; p.W = im.W; p.Cin = b.Cin; p.Cout = b.Cout; p.relu = b.relu;
+        p.tiles_x = im.tiles_x; p.tiles_y = 0; p.partial = nullptr; p.partial_floats = 0; p.ksplit = 1;
+        p.in2 = im.in2; p.Cin2 = b.Cin2; p.wt2_bf = nullptr; p.bits_out = im.bits_out; p.bits_in = im.bits_in;
+        p.pool_out = im.pool_out;
+        p.wt_h2 = b.wt_h2; p.wt_h2_inv = b.wt_h2_inv; p.wt2_f32 = im.wt2_f32;
+        p.amax_in = im.amax_in; p.amax_in2 = im.amax_in2; p.amax_w2 = im.amax_w2; p.amax_out = im.amax_out;
+        p.pcode_in = im.pcode_in; p.pcode_out = im.pcode_out;
+        p.in2_row0 = im.in2_row0; p.in2_rows = im.in2_rows; p.ty0 = 0;
+        sp = sp_all - (i ? b.img[i - 1].tile_end : 0);
+        return true;
+    }
+};
+
 template <int TH, int BN, int NTW, int KC, bool UNPOOL, bool M16>
 __global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), (H2Cfg<TH, BN, NTW, KC>::WAVES_PER_EU)) void conv_h2_kernel(ConvParams p) {
-    const int n_ct = p.Cout / BN;
-    const int t = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-    conv_h2_body<TH, BN, NTW, KC, UNPOOL, M16>(p, t / n_ct, t % n_ct, blockIdx.x);
+    conv_h2_body<TH, BN, NTW, KC, UNPOOL, M16>(H2OneTile{p, p.Cout / BN}, blockIdx.x);
 }
 
 // One launch = one layer over several images (the pyramid levels of a closure), see conv_bf3.hip.
-template <int TH, int BN, int NTW, int KC, bool UNPOOL, bool M16>
+template <int TH, int BN, int NTW, int KC, bool UNPOOL, bool M16, bool PERSIST>
 __global__ __launch_bounds__((H2Cfg<TH, BN, NTW, KC>::NT), (H2Cfg<TH, BN, NTW, KC>::WAVES_PER_EU)) void conv_h2_batch_kernel(ConvBatch b) {
-    const int n_ct = b.Cout / BN;
-    const int t = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
-    const int sp_all = t / n_ct;
-    int i = 0;
-    while (i + 1 < b.n && sp_all >= b.img[i].tile_end) ++i;
-    const ConvImage& im = b.img[i];
-    ConvParams p;
-    p.in = im.in; p.wt = nullptr; p.wt_bf = nullptr; p.bias = b.bias; p.addend = im.addend; p.mask = im.mask; p.out = im.out;
-    p.H = im.H; p.W = im.W; p.Cin = b.Cin; p.Cout = b.Cout; p.relu = b.relu;
-    p.tiles_x = im.tiles_x; p.tiles_y = 0; p.partial = nullptr; p.partial_floats = 0; p.ksplit = 1;
-    p.in2 = im.in2; p.Cin2 = b.Cin2; p.wt2_bf = nullptr; p.bits_out = im.bits_out; p.bits_in = im.bits_in;
-    p.pool_out = im.pool_out;
-    p.wt_h2 = b.wt_h2; p.wt_h2_inv = b.wt_h2_inv; p.wt2_f32 = im.wt2_f32;
-    p.amax_in = im.amax_in; p.amax_in2 = im.amax_in2; p.amax_w2 = im.amax_w2; p.amax_out = im.amax_out;
-    p.pcode_in = im.pcode_in; p.pcode_out = im.pcode_out;
-    p.in2_row0 = im.in2_row0; p.in2_rows = im.in2_rows; p.ty0 = 0;
-    conv_h2_body<TH, BN, NTW, KC, UNPOOL, M16>(p, sp_all - (i ? b.img[i - 1].tile_end : 0), t % n_ct, blockIdx.x);
+    conv_h2_body<TH, BN, NTW, KC, UNPOOL, M16>(H2BatchTiles<PERSIST>{b, b.Cout / BN}, blockIdx.x);
 }
+// the shapes the persistent form is built for: the ones whose launches have more tiles than the chip holds workgroups
+template <int TH, int BN, int NTW, int KC>
+constexpr bool h2_persist_shape = (KC == 16) || (TH == 16 && NTW == 2 && KC == 32);
 
 template <int TH, int BN, int NTW, int KC, bool UNPOOL, bool M16>
 static hipError_t init_form() {
@@ -1160,8 +1273,14 @@ static hipError_t init_form() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_kernel<TH, BN, NTW, KC, UNPOOL, M16>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_batch_kernel<TH, BN, NTW, KC, UNPOOL, M16>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_batch_kernel<TH, BN, NTW, KC, UNPOOL, M16, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if constexpr (h2_persist_shape<TH, BN, NTW, KC> && !M16) {
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_h2_batch_kernel<TH, BN, NTW, KC, UNPOOL, false, true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    }
+    return e;
 }
 template <int TH, int BN, int NTW, int KC, bool UNPOOL>
 static hipError_t init_one() {
@@ -1209,13 +1328,20 @@ static void launch_batch_cfg(const ConvBatch& b, int blocks, hipStream_t stream)
     constexpr int nt = H2Cfg<TH, BN, NTW, KC>::NT;
     if constexpr (KC == 32 && NTW <= 2) {
         if (b.mfma16 >= 2 || (b.mfma16 == 1 && TH == 8)) {
-            if (b.unpool) hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, true, true>), dim3(blocks), dim3(nt), lds, stream, b);
-            else hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, false, true>), dim3(blocks), dim3(nt), lds, stream, b);
+            if (b.unpool) hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, true, true, false>), dim3(blocks), dim3(nt), lds, stream, b);
+            else hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, false, true, false>), dim3(blocks), dim3(nt), lds, stream, b);
             return;
         }
     }
-    if (b.unpool) hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, true, false>), dim3(blocks), dim3(nt), lds, stream, b);
-    else hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, false, false>), dim3(blocks), dim3(nt), lds, stream, b);
+    if constexpr (h2_persist_shape<TH, BN, NTW, KC>) {
+        if (b.persist) {
+            if (b.unpool) hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, true, false, true>), dim3(blocks), dim3(nt), lds, stream, b);
+            else hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, false, false, true>), dim3(blocks), dim3(nt), lds, stream, b);
+            return;
+        }
+    }
+    if (b.unpool) hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, true, false, false>), dim3(blocks), dim3(nt), lds, stream, b);
+    else hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, false, false, false>), dim3(blocks), dim3(nt), lds, stream, b);
 }
 template <int TH, int BN, int NTW, int KC>
 static void launch_single_cfg(const ConvParams& p, int blocks, hipStream_t stream) {
@@ -1262,7 +1388,18 @@ hipError_t launch_conv_h2_batch(const ConvBatch& b0, hipStream_t stream) {
         tiles += b.img[i].tiles_x * ((b.img[i].H + th - 1) / th);
         b.img[i].tile_end = tiles;
     }
-    const int blocks = tiles * (b.Cout / bn);
+    int blocks = tiles * (b.Cout / bn);
+    // Persistent form (nst_options.h2_persist): as many workgroups as the chip holds at once (256 CUs x 1 or 2 by the
+    // shape's LDS / thread budget), each walking its share of the tiles with the K pipeline chained across them.  Not for
+    // launches with a second K source (its stages use the LDS buffers the chained prologue would be staged in).
+    bool second = false;
+    for (int i = 0; i < b.n; ++i) second = second || (b.img[i].in2 != nullptr);
+    const int resident = 256 * ((!wide || shortk || th == 4) ? 2 : 1);
+    b.total_tiles = blocks;
+    const bool m16 = b.mfma16 >= 2 || (b.mfma16 == 1 && th == 8);      // (the 16x16x32 form has no persistent build)
+    const bool pshape = !wide || shortk || (th == 16 && !b.wg256);
+    b.persist = (b.persist && !second && b.Cin > 0 && blocks > resident && pshape && !m16) ? 1 : 0;
+    if (b.persist) blocks = resident;
     if (!wide) launch_batch_cfg<16, 64, 2, 16>(b, blocks, stream);
     else if (shortk) launch_batch_cfg<8, 128, 2, 16>(b, blocks, stream);
     else if (th == 4) launch_batch_cfg<4, 128, 1, 32>(b, blocks, stream);

@@ -104,6 +104,10 @@ struct nst_ctx {
     int mfma16 = 1;             // nst_options.h2_mfma16
     int wg256 = 0;              // nst_options.h2_wg256
     int tile_rows = 0;          // nst_options.h2_tile_rows
+    int gram_overlap = 0;       // nst_options.gram_overlap
+    int persist = 1;            // nst_options.h2_persist
+    hipStream_t side = nullptr; // the Gram launches of the shallow style layers run here, under the deeper forward convolutions
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
     hipEvent_t tail = nullptr;  // recorded after the last launch that touches context-owned memory: what
                                 // nst_job_configure / nst_ctx_destroy wait for instead of the whole device
     int batched = 1;            // 1: one conv launch per layer covering every pyramid level (one stream)
@@ -526,7 +530,11 @@ constexpr size_t kWinGramOff[5] = {0, 64 * 64, 64 * 64 + 128 * 128, 64 * 64 + 12
 constexpr size_t kWinScalarOff = 64 * 64 + 128 * 128 + 256 * 256 + 2 * 512 * 512;    // content SSE, TV x, TV y
 constexpr size_t kWinSums = kWinScalarOff + 4;
 
-int batched_forward(nst_ctx* ctx, const float* const* xi, const int* lv, int n, hipStream_t s, const Window* win) {
+// `fork_sw` >= 0 (f16x2 closure, nst_options.gram_overlap): once relu3_1 is written, the Gram matrices of relu1_1, relu2_1 and
+// relu3_1 - HBM-bound streams over 85 % of the style bytes - are launched on the context's side stream, where they run
+// under the MFMA-bound convolutions of conv3_2 ... conv5_1 instead of after them; the caller joins before the backward.
+int batched_gram(nst_ctx* ctx, const int* lv, int n, float sw, hipStream_t s, unsigned qmask);
+int batched_forward(nst_ctx* ctx, const float* const* xi, const int* lv, int n, hipStream_t s, const Window* win, float fork_sw = -1.f) {
     const bool h2 = ctx->conv_mode == 2;
     for (int k = 0; k < n; ++k) {
         LevelWs& L = ctx->lv[lv[k]];
@@ -547,7 +555,7 @@ int batched_forward(nst_ctx* ctx, const float* const* xi, const int* lv, int n, 
         const int pk = pool_index_after(l - 1), pa = pool_index_after(l);
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wf_bf[l]; b.bias = ctx->bias[l]; b.Cin = kCin[l]; b.Cout = kCout[l]; b.relu = 1;
-        b.wt_h2 = ctx->wf_h2[l]; b.wt_h2_inv = ctx->wf_h2_inv[l]; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows;
+        b.wt_h2 = ctx->wf_h2[l]; b.wt_h2_inv = ctx->wf_h2_inv[l]; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows; b.persist = ctx->persist;
         double flops = 0;
         for (int k = 0; k < n; ++k) {
             ActSet& a = ctx->lv[lv[k]].acts;
@@ -562,14 +570,22 @@ int batched_forward(nst_ctx* ctx, const float* const* xi, const int* lv, int n, 
             im.amax_in = amax_act(a, l - 1); im.amax_out = amax_act(a, l);
             flops += conv_flops(im.H, im.W, b.Cin, b.Cout, 9);
         }
-        Timer t(ctx, s, K_CONV3, flops, b.img[0].H, b.img[0].W, b.Cin, b.Cout, 9, l);
-        HIPCHK(ctx, h2 ? launch_conv_h2_batch(b, s) : launch_conv_bf3_batch(b, s));
+        {
+            Timer t(ctx, s, K_CONV3, flops, b.img[0].H, b.img[0].W, b.Cin, b.Cout, 9, l);
+            HIPCHK(ctx, h2 ? launch_conv_h2_batch(b, s) : launch_conv_bf3_batch(b, s));
+        }
+        if (l == 4 && fork_sw >= 0.f && ctx->side) {
+            HIPCHK(ctx, hipEventRecord(ctx->side_fork, s));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->side_fork, 0));
+            NSTCHK(batched_gram(ctx, lv, n, fork_sw, ctx->side, 0x07u));
+            HIPCHK(ctx, hipEventRecord(ctx->side_join, ctx->side));
+        }
     }
     return NST_OK;
 }
 
 // ---- style losses: Gram matrices, S = d loss / d G folded for the backward
-int batched_gram(nst_ctx* ctx, const int* lv, int n, float sw, hipStream_t s) {
+int batched_gram(nst_ctx* ctx, const int* lv, int n, float sw, hipStream_t s, unsigned qmask) {
     const bool h2 = ctx->conv_mode == 2;
     if (h2) {
         // every (level, style layer) pair in two partial launches (one per tile shape) and one finish launch
@@ -579,6 +595,7 @@ int batched_gram(nst_ctx* ctx, const int* lv, int n, float sw, hipStream_t s) {
             for (int k = k0; k < n && k < k0 + 3; ++k) {
                 LevelWs& L = ctx->lv[lv[k]];
                 for (int q = 0; q < 5; ++q) {
+                    if (!((qmask >> q) & 1u)) continue;
                     const int l = kStyleLayer[q];
                     const int C = kCout[l];
                     const size_t N = (size_t)L.acts.h[l] * L.acts.w[l];
@@ -593,6 +610,7 @@ int batched_gram(nst_ctx* ctx, const int* lv, int n, float sw, hipStream_t s) {
                     flops += 2.0 * (double)N * C * C;
                 }
             }
+            if (gb.n == 0) continue;
             Timer t(ctx, s, K_GRAM, flops);
             HIPCHK(ctx, launch_gram_batch(gb, s));
         }
@@ -622,7 +640,7 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
         // its own (no 3x3 part), one launch for all levels; its epilogue applies the ReLU mask and records the absmax
         const int l = NL - 1;
         ConvBatch b{};
-        b.n = n; b.Cin = 0; b.Cout = kCout[l]; b.Cin2 = kCout[l]; b.relu = 0; b.wt_h2_inv = 1.f; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows;
+        b.n = n; b.Cin = 0; b.Cout = kCout[l]; b.Cin2 = kCout[l]; b.relu = 0; b.wt_h2_inv = 1.f; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows; b.persist = ctx->persist;
         double flops = 0;
         for (int k = 0; k < n; ++k) {
             LevelWs& L = ctx->lv[lv[k]];
@@ -654,7 +672,7 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
         for (int q = 0; q < 5; ++q) if (kStyleLayer[q] == m) style_q = q;
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wd_bf[l]; b.bias = nullptr; b.Cin = kCout[l]; b.Cout = kCin[l]; b.relu = 0;
-        b.wt_h2 = ctx->wd_h2[l]; b.wt_h2_inv = ctx->wd_h2_inv[l]; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows;
+        b.wt_h2 = ctx->wd_h2[l]; b.wt_h2_inv = ctx->wd_h2_inv[l]; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows; b.persist = ctx->persist;
         // f16x2: when a max-pool follows layer l, cur[] holds the gradient w.r.t. the POOLED map and this launch's
         // loader un-pools it through the arg-max code (no un-pool kernel, no full-size gradient round trip)
         const int pl = pool_index_after(l);
@@ -731,8 +749,11 @@ int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsi
         else HIPCHK(ctx, launch_zero(gi[i], (size_t)3 * ctx->lv[i].h * ctx->lv[i].w, s));
     }
     if (n == 0) return NST_OK;
-    NSTCHK(batched_forward(ctx, xi, lv, n, s, nullptr));
-    NSTCHK(batched_gram(ctx, lv, n, sw, s));
+    // (not while a hipGraph is being captured or replayed: the closure then stays on one stream)
+    const bool overlap = ctx->gram_overlap && ctx->conv_mode == 2 && !ctx->use_graph && ctx->side != nullptr;
+    NSTCHK(batched_forward(ctx, xi, lv, n, s, nullptr, overlap ? sw : -1.f));
+    NSTCHK(batched_gram(ctx, lv, n, sw, s, overlap ? 0x18u : 0x1Fu));
+    if (overlap) HIPCHK(ctx, hipStreamWaitEvent(s, ctx->side_join, 0));
     return batched_backward(ctx, xi, gi, lv, n, cw, tvw, s, nullptr, nullptr, 0, 0);
 }
 
@@ -787,6 +808,7 @@ void quiesce(nst_ctx* ctx) {
     for (int i = 0; i < NST_MAX_LEVELS; ++i)
         if (ctx->lv[i].stream) (void)hipStreamSynchronize(ctx->lv[i].stream);
     if (ctx->gstream) (void)hipStreamSynchronize(ctx->gstream);
+    if (ctx->side) (void)hipStreamSynchronize(ctx->side);
 }
 
 int env_flag(const char* name, int dflt) {
@@ -817,7 +839,7 @@ void nst_options_default(nst_options* o) {
     if (!o) return;
     o->struct_size = (int)sizeof(nst_options);
     o->conv_mode = -1; o->batched = -1; o->single_stream = -1; o->use_graph = -1; o->h2_band_rows = -1; o->lbfgs_gram = -1;
-    o->h2_mfma16 = -1; o->h2_wg256 = -1; o->h2_tile_rows = -1;
+    o->h2_mfma16 = -1; o->h2_wg256 = -1; o->h2_tile_rows = -1; o->gram_overlap = -1; o->h2_persist = -1;
 }
 
 int nst_ctx_create(int device, const float* const* weights, const float* const* biases, nst_ctx** out) {
@@ -866,6 +888,8 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
     ctx->mfma16 = opts.h2_mfma16 >= 0 ? opts.h2_mfma16 : env_flag("NST_H2_MFMA16", 1);
     ctx->wg256 = (opts.h2_wg256 >= 0 ? opts.h2_wg256 : env_flag("NST_H2_WG256", 0)) ? 1 : 0;
     ctx->tile_rows = opts.h2_tile_rows >= 0 ? opts.h2_tile_rows : env_flag("NST_H2_TILE_ROWS", 0);
+    ctx->persist = (opts.h2_persist >= 0 ? opts.h2_persist : env_flag("NST_H2_PERSIST", 0)) ? 1 : 0;
+    ctx->gram_overlap = (opts.gram_overlap >= 0 ? opts.gram_overlap : env_flag("NST_GRAM_OVERLAP", 0)) ? 1 : 0;
     if (ctx->use_graph && hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "stream creation failed"; return bail(NST_E_HIP); }
     if (e != hipSuccess) { ctx->err = std::string("kernel attribute setup: ") + hipGetErrorString(e); return bail(NST_E_HIP); }
 
@@ -929,6 +953,13 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
             if (hipMemcpy(ctx->wd_h2[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
         }
     }
+    if (ctx->gram_overlap && ctx->conv_mode == 2 &&
+        (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
+         hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
+         hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess)) {
+        ctx->err = "side stream creation failed";
+        return bail(NST_E_HIP);
+    }
     if (hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->tail, hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->t0) != hipSuccess || hipEventCreate(&ctx->t1) != hipSuccess) {
@@ -949,6 +980,9 @@ void nst_ctx_destroy(nst_ctx* ctx) {
     dev_free(ctx->w11k); dev_free(ctx->w11d);
     if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
     if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
+    if (ctx->side) (void)hipStreamDestroy(ctx->side);
+    if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+    if (ctx->side_join) (void)hipEventDestroy(ctx->side_join);
     if (ctx->fork) (void)hipEventDestroy(ctx->fork);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);

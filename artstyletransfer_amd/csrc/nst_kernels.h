@@ -92,6 +92,8 @@ struct ConvBatch {
     float wt_h2_inv;
     int unpool;              // every image's `in` is a pooled gradient to be un-pooled through pcode_in
     int mfma16, wg256, tile_rows;   // conv_h2: see ConvParams
+    int persist;             // conv_h2: in: nst_options.h2_persist; the launcher clears it where the persistent form does not apply
+    int total_tiles;         // conv_h2: filled by the launcher (tiles x output-channel tiles)
 };
 
 // conv_mfma.hip

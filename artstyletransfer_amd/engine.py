@@ -39,7 +39,8 @@ class StyleEngine:
                  conv_mode: Optional[str] = None, batched: Optional[bool] = None, single_stream: Optional[bool] = None,
                  use_graph: Optional[bool] = None, h2_band_rows: Optional[int] = None, lbfgs_gram: Optional[bool] = None,
                  h2_mfma16: Optional[bool] = None, h2_wg256: Optional[bool] = None,
-                 h2_tile_rows: Optional[int] = None):
+                 h2_tile_rows: Optional[int] = None, gram_overlap: Optional[bool] = None,
+                 h2_persist: Optional[bool] = None):
         """Options (nst_options): None = environment variable (NST_CONV, NST_BATCH, NST_SINGLE_STREAM, NST_GRAPH,
         NST_H2_BAND_ROWS, NST_LBFGS_GRAM, NST_H2_MFMA16; read once, here) and otherwise the default (f16x2, batched, ...)."""
         self.lib = _lib.load()
@@ -64,7 +65,8 @@ class StyleEngine:
             opts.conv_mode = _lib.CONV_MODES[conv_mode]
         for name, val in (("batched", batched), ("single_stream", single_stream), ("use_graph", use_graph),
                           ("h2_band_rows", h2_band_rows), ("lbfgs_gram", lbfgs_gram), ("h2_mfma16", h2_mfma16),
-                          ("h2_wg256", h2_wg256), ("h2_tile_rows", h2_tile_rows)):
+                          ("h2_wg256", h2_wg256), ("h2_tile_rows", h2_tile_rows),
+                          ("gram_overlap", gram_overlap), ("h2_persist", h2_persist)):
             if val is not None:
                 setattr(opts, name, int(val))
         ctx = C.c_void_p()
@@ -436,14 +438,19 @@ class PixelOptimizer:
                    "nst_opt_shard_levels")
 
     def shard_stripes(self, rank: int, world: int, weights, content_t: torch.Tensor, style_t: torch.Tensor,
-                      dist_mod=None, group=None) -> None:
+                      dist_mod=None, group=None, comm: "Communicator" = None) -> None:
         """Spatial sharding of the top level (SURVEY 8(e) partition B, halo recompute) on top of level sharding of the
         rest: every rank evaluates a horizontal stripe of level 0 (its rows + a 96-row halo, a second engine) and its
         share of the lower levels.  Per closure: one all-reduce of the Gram / content / TV sums between the stripe's
         forward and backward pass, one of the pixel gradient and the loss rows at the end.  content_t / style_t: the
-        prepared (1,3,H0,W0) content and (1,3,hs,ws) style images of level 0."""
+        prepared (1,3,H0,W0) content and (1,3,hs,ws) style images of level 0.
+        `comm` (a Communicator): both collectives go through the C ABI's RCCL communicator (nst_comm_allreduce_sum on
+        the job's stream; gradient and loss row are ONE packed buffer, as in nst_opt_shard_levels_comm) and rank / world
+        are the communicator's; otherwise through `dist_mod` (torch.distributed: gloo rehearsals, or nccl)."""
         from . import sharding
-        if dist_mod is None:
+        if comm is not None:
+            rank, world = comm.rank, comm.world
+        elif dist_mod is None:
             import torch.distributed as dist_mod
         e = self.engine
         H, W = e.shape
@@ -452,8 +459,10 @@ class PixelOptimizer:
         stripe.configure(1, plan.ext_rows, W)
         stripe.set_targets(0, plan.cut(content_t), style_t.contiguous())
         self._stripe, self._plan = stripe, plan
-        self._g = torch.zeros((1, 3, H, W), dtype=torch.float32, device=e.device)
-        self._l = torch.zeros(self.row, dtype=torch.float32, device=e.device)
+        n = 3 * H * W
+        self._pack = torch.zeros(n + self.row, dtype=torch.float32, device=e.device)
+        self._g = self._pack[:n].view(1, 3, H, W)
+        self._l = self._pack[n:]
         # lower levels: level l >= 1 on rank l % world; level 0 is nobody's in the level mask (its stripes are added here)
         mask = 0
         for l in range(1, e.levels):
@@ -464,12 +473,19 @@ class PixelOptimizer:
             x, (cw, sw, tvw) = self._x, self._w
             xs = plan.cut(x)
             sums = stripe.window_begin(xs, plan.row0, plan.rows, H)
-            dist_mod.all_reduce(sums, op=dist_mod.ReduceOp.SUM, group=group)
+            if comm is not None:
+                comm.allreduce_sum(sums)
+            else:
+                dist_mod.all_reduce(sums, op=dist_mod.ReduceOp.SUM, group=group)
             gxs, row = stripe.window_end(xs, plan.row0, plan.rows, H, cw, sw, tvw, sums)
             plan.add_into(self._g, gxs)
             if rank == 0:                      # every rank holds the same level-0 row: one contributor
                 self._l[0:4] = row[0:4]
-            sharding.allreduce_closure(self._g, self._l, dist_mod, group)
+            if comm is not None:
+                comm.allreduce_sum(self._pack)
+                sharding.reform_total(self._l)
+            else:
+                sharding.allreduce_closure(self._g, self._l, dist_mod, group)
 
         self._hook = _lib.REDUCE_HOOK(hook)
         _lib.check(e.ctx, e.lib.nst_opt_shard_levels(self.h, mask, _ptr(self._g), _ptr(self._l), self._hook, None),

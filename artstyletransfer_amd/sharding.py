@@ -37,10 +37,13 @@ def allreduce_closure(grad: torch.Tensor, losses: torch.Tensor, dist_mod=None, g
         import torch.distributed as dist_mod
     dist_mod.all_reduce(grad, op=dist_mod.ReduceOp.SUM, group=group)
     dist_mod.all_reduce(losses, op=dist_mod.ReduceOp.SUM, group=group)
-    # Every level row has exactly one non-zero contributor, so the rows are exact; the grand total is re-formed
-    # from them in level order - the association the unsharded closure (and the reference, :179-185) uses.
-    # L-BFGS' accept test `f_new < f` flips on a one-ulp difference, so this keeps sharded and unsharded runs
-    # on the same branch.
+    reform_total(losses)
+
+
+def reform_total(losses: torch.Tensor) -> None:
+    """Every level row has exactly one non-zero contributor, so the summed rows are exact; the grand total is re-formed
+    from them in level order - the association the unsharded closure (and the reference, :179-185) uses.  L-BFGS'
+    accept test `f_new < f` flips on a one-ulp difference, so this keeps sharded and unsharded runs on the same branch."""
     levels = (losses.numel() - 1) // 4
     total = losses[0].clone()
     for l in range(1, levels):

@@ -378,18 +378,20 @@ def main():
     cfg.optimizer = args.optimizer
     opt = PixelOptimizer(eng, args.optimizer, 10.0, args.lbfgs_max_eval)
     comm = None
+    if sharded and args.comm == "c-abi" and args.dist_backend == "nccl" and not args.share_gpu:
+        # the collectives behind the C ABI (nst_comm_*: RCCL resolved by the library itself); the id travels over the process group
+        ids = [Communicator.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        comm = Communicator(local_rank, rank, world, ids[0])
+    prep = lambda a: eng.prepare_img(torch.from_numpy(a).to(x.device))
     if sharded and args.mode == "levels":
-        if args.comm == "c-abi" and args.dist_backend == "nccl" and not args.share_gpu:
-            ids = [Communicator.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = Communicator(local_rank, rank, world, ids[0])
+        if comm is not None:
             opt.shard_levels_comm(comm)
         else:
             opt.shard_levels(rank, world, dist)
     elif sharded:
         # the top level cut into horizontal stripes (+ halo), the lower levels dealt out by level
-        prep = lambda a: eng.prepare_img(torch.from_numpy(a).to(x.device))
-        opt.shard_stripes(rank, world, job_host[3], prep(job_host[0][0]), prep(job_host[1][0]), dist)
+        opt.shard_stripes(rank, world, job_host[3], prep(job_host[0][0]), prep(job_host[1][0]), dist, comm=comm)
     w3 = (cfg.content_weight, cfg.style_weight, cfg.tv_weight)
     cw, sw, tvw = w3
     H, W = eng.shape
@@ -482,7 +484,8 @@ def main():
                                         + (" behind the C ABI (nst_comm)" if comm is not None else " through torch.distributed")
                                         if args.mode == "levels" else
                                         f"top level in {world} stripes (+96-row halo), lower levels by level; all-reduce of the "
-                                        f"Gram/content/TV sums and of the pixel gradient per closure")
+                                        f"Gram/content/TV sums and of the packed pixel gradient + loss row per closure"
+                                        + (" behind the C ABI (nst_comm)" if comm is not None else " through torch.distributed"))
                                        if sharded else (f"{args.jobs_per_gpu} job(s) per GPU on their own streams, no collective" if args.jobs_per_gpu > 1 else "1 job per GPU, no collective")),
                        "final_loss": float(last_rows[-1][-1]) if last_rows is not None else None,
                        "job_setup_ms_on_device": round(getattr(cfg, "job_setup_ms", 0.0), 1)},

@@ -84,6 +84,13 @@ typedef struct nst_options {
                              -1: env NST_H2_WG256, default 0 */
     int h2_tile_rows;     /* f16x2 convolutions with 128-channel tiles and 32-channel chunks: 4 / 8 / 16 = pixel rows per workgroup tile,
                              0 = chosen per launch from the number of workgroups; -1: env NST_H2_TILE_ROWS, default 0 */
+    int gram_overlap;     /* f16x2 closure: 1 = the Gram matrices of relu1_1 ... relu3_1 (HBM-bound) run on a side stream of the
+                             context under the MFMA-bound convolutions of conv3_2 ... conv5_1, joined before the backward pass;
+                             0 = everything in order on the caller's stream; -1: env NST_GRAM_OVERLAP, default 0 (measured: no gain) */
+    int h2_persist;       /* f16x2 batched launches: 1 = persistent workgroups (one grid that fills the chip once, each workgroup
+                             walks its share of the tiles with the K pipeline chained from one tile into the next);
+                             0 = one workgroup per tile; -1: env NST_H2_PERSIST, default 0 (measured: the chained form's extra scalar state
+                             costs more than the hidden prologues gain) */
 } nst_options;
 void nst_options_default(nst_options* opts);
 int nst_ctx_create_ex(int device, const float* const* weights, const float* const* biases, const nst_options* opts,

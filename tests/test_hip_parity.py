@@ -291,6 +291,33 @@ def test_closure_execution_modes_agree(eng, vgg_weights, opts):
         other.close()
 
 
+@pytest.mark.parametrize("h,w,nlev", [(512, 768, 2), (400, 600, 3), (528, 336, 2)])
+def test_persistent_launches_are_bitwise_the_one_tile_launches(vgg_weights, h, w, nlev):
+    """nst_options.h2_persist: a layer's launch as workgroups that stay resident and walk several tiles, the K pipeline
+    chained from one tile into the next (conv_h2.hip), against one workgroup per tile.  A tile's arithmetic does not depend
+    on how its workgroup reached it, so gradient and loss rows must agree BITWISE - on images large enough that the
+    persistent form is actually taken (more tiles than the chip holds workgroups), with edge tiles (600 = 37.5 x 16,
+    336 = 21 x 16 wide) and several levels in one launch."""
+    from artstyletransfer_amd.engine import StyleEngine
+    c, s = _levels(h, w, nlev, 21), _levels(h - 64, w - 32, nlev, 22)
+    xt = cpu_ref.prepare_img((0.6 * c[0] + 0.4 * cpu_ref.synthetic_image(h, w, seed=23)).astype(np.float32))
+    x = dev(xt)
+    out = []
+    for persist in (True, False):
+        e = StyleEngine(vgg_weights, 0, h2_persist=persist)
+        try:
+            _setup(e, c, s)
+            g, l = e.closure(x, CW, SW, TVW)
+            g2, l2 = e.closure(x, CW, SW, TVW)                  # and again: reproducible from call to call
+            assert torch.equal(g, g2) and torch.equal(l, l2)
+            out.append((g.cpu().numpy().copy(), l.cpu().numpy().copy()))
+        finally:
+            e.close()
+    assert np.isfinite(out[0][0]).all() and np.abs(out[0][0]).max() > 0
+    assert np.array_equal(out[0][0], out[1][0]), rel_l2(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+
+
 def test_options_default_to_the_environment(vgg_weights, monkeypatch):
     """nst_options fields left at -1 take the environment, read once at context creation; an explicit option wins."""
     from artstyletransfer_amd.engine import StyleEngine

@@ -82,11 +82,17 @@ def test_failed_step_frees_the_optimiser(vgg_weights, monkeypatch):
     monkeypatch.setattr(engine.PixelOptimizer, "step", failing_step)
     with pytest.raises(RuntimeError, match="injected"):
         asyncio.run(run())
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     base = _free_bytes()
     for _ in range(2):
         with pytest.raises(RuntimeError, match="injected"):
             asyncio.run(run())
+    # (the raised exceptions' tracebacks hold the job's frames - and through them its image tensors, each in a 20 MB
+    # segment of torch's allocator - in reference cycles until the collector runs)
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     # Adam state of one leaked job = 3 x 12*H*W bytes + the 160 MB workspace; torch's per-stream cache keeps <= 2 MB per job
     assert base - _free_bytes() < 16 << 20
@@ -213,6 +219,24 @@ def test_comm_single_rank_and_sharded_driver(vgg_weights):
         comm.close()
 
 
+def test_stripe_sharding_through_the_c_communicator_world_of_one():
+    """Stripe mode with both collectives on the C ABI's communicator (PixelOptimizer.shard_stripes(comm=...)): a world of
+    one on this GPU - the top level goes through the window closure as ONE stripe, the Gram / content / TV sums and the
+    packed gradient + loss row through ncclAllReduce - against the unsharded optimiser: same accept / reject sequence,
+    loss rows to 1e-5 (tools/check_sharded_opt.py; two ranks run in the test below where the box has two GPUs)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NST_SYNTHETIC_WEIGHTS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "check_sharded_opt.py"), "stripes", "--c-abi-comm",
+                          "--levels", "2", "--steps", "3"], env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "SHARDED == UNSHARDED" in out.stdout
+    assert "comm (rank, world, calls, bytes) (0, 1," in out.stdout
+
+
 @pytest.mark.parametrize("mode", ["levels", "stripes"])
 def test_sharded_job_over_rccl_matches_the_unsharded_job(mode):
     """Two ranks on two GPUs over RCCL (skipped on a one-GPU box): tools/check_sharded_opt.py runs the optimiser sharded
@@ -225,7 +249,7 @@ def test_sharded_job_over_rccl_matches_the_unsharded_job(mode):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", NST_SYNTHETIC_WEIGHTS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
            "--master-port", "29517", os.path.join(root, "tools", "check_sharded_opt.py"), mode, "--backend", "nccl",
-           "--c-abi-comm" if mode == "levels" else "--torch-comm"]
+           "--c-abi-comm"]
     out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "SHARDED == UNSHARDED" in out.stdout
