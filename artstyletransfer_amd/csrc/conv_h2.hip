@@ -598,7 +598,15 @@ __device__ __forceinline__ void conv_h2_body(const Tiles& tiles, const int slot_
             Look ahead = here;
             if (last && chain) ahead = there();
             const int to = opaque(tid);
-            constexpr int AH = (C::A_PER_T + 1) / 2;      // the next patch is staged in two halves (registers)
+            // The next patch is staged through registers in two halves (loaded at taps 0 / 4, cut into LDS at 3 / 7), or -
+            // the 16x16x32 form on the 64 x 64 wave tile, which is four registers short otherwise and spills one staging unit
+            // per half INSIDE the loop (buffer_load; s_waitcnt vmcnt(0); scratch_store) - in thirds (taps 0 / 3 / 6 -> 2 / 5 / 8)
+#ifndef NST_H2_THIRDS_ALL
+#define NST_H2_THIRDS_ALL 0
+#endif
+            constexpr int PARTS = ((NST_H2_THIRDS_ALL || (M16 && NTW == 2)) && C::A_PER_T % 3 == 0) ? 3 : 2;
+            constexpr int AP = (C::A_PER_T + PARTS - 1) / PARTS;
+            auto part_lo = [](int j) { return j * AP < C::A_PER_T ? j * AP : C::A_PER_T; };
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 // top of stage g = 9 c + t: slice g+2 to LDS, slice g+3 on its way
@@ -621,13 +629,21 @@ __device__ __forceinline__ void conv_h2_body(const Tiles& tiles, const int slot_
                     if (t + 3 < 9) load_b(rb, c, t + 3, to, n0);
                     else load_b(rb, cn, t + 3 - 9, to, ahead.n0);
                 }
-                if (t == 0) load_a(ra, ahead, cn, 0, AH, to);
-                if (t == 4) load_a(ra, ahead, cn, AH, C::A_PER_T, to);
+                if constexpr (PARTS == 2) {
+                    if (t == 0) load_a(ra, ahead, cn, 0, AP, to);
+                    if (t == 4) load_a(ra, ahead, cn, AP, C::A_PER_T, to);
+                } else {
+                    if (t % 3 == 0) load_a(ra, ahead, cn, part_lo(t / 3), part_lo(t / 3 + 1), to);
+                }
                 // keep the loads HERE: left free, the scheduler sinks them towards the end of the stage (their
                 // registers are then shared with the fragments) and the next stage stalls on them
                 __builtin_amdgcn_sched_barrier(0);
-                if (t == 3) store_a(anext, ahead.sa, ra, 0, AH, to, UNPOOL ? rc : nullptr, bit0_of(cn));
-                if (t == 7) store_a(anext, ahead.sa, ra, AH, C::A_PER_T, to, UNPOOL ? rc : nullptr, bit0_of(cn));
+                if constexpr (PARTS == 2) {
+                    if (t == 3) store_a(anext, ahead.sa, ra, 0, AP, to, UNPOOL ? rc : nullptr, bit0_of(cn));
+                    if (t == 7) store_a(anext, ahead.sa, ra, AP, C::A_PER_T, to, UNPOOL ? rc : nullptr, bit0_of(cn));
+                } else {
+                    if (t % 3 == 2) store_a(anext, ahead.sa, ra, part_lo(t / 3), part_lo(t / 3 + 1), to, UNPOOL ? rc : nullptr, bit0_of(cn));
+                }
                 const unsigned char* bcur = ldsB + (t % 3) * C::B_BYTES;
                 const unsigned char* anxt = (t + 1 < 9) ? acur + tap_off(t + 1) : anext + tap_off(0);
                 const unsigned char* bnxt = ldsB + ((t + 1) % 3) * C::B_BYTES;
@@ -1317,17 +1333,23 @@ static int h2_tile_rows(int Cout, long blocks16, int forced = 0) {
     return blocks16 < 400 ? 8 : 16;
 }
 
-// The 16x16x32 form exists for the 32-channel-chunk shapes.  `mfma16` = nst_options.h2_mfma16: 1 (default) = on the
-// 8-row shape (64 x 32 wave tiles, 186 registers: +6 ... 11 % per launch, L=1 closure +1.6 %); 2 = on every shape it
-// exists for - slower on the 4-row shape (L=0 closure -3 %) and on the 64 x 64 wave-tile shape, where it needs ~20
-// registers more than the 256 a wave has at two waves per SIMD: the patch staging registers spill inside the K loop and
-// the launch is 5-20 % SLOWER (profiles/r02_mfma_shape_experiments.txt); 0 = off.
+// The 16x16x32 form exists for the 32-channel-chunk shapes (profiles/r02_mfma_shape_experiments.txt).
+// nst_options.h2_mfma16: 0 = never; 1 (default) = the 8-row shape (64 x 32 wave tiles, 180 registers: +6 ... 11 % per launch);
+// 2 = that and the 16-row 64 x 64 wave-tile shape where the launch does not un-pool - with the patch staged in thirds its K loop
+// has no spill stores left, and over a sustained run (300 closures) the L=2 closure is 9.08 against 9.00 ms: no gain over
+// 32x32x16 on that shape; 3 = wherever the form is built (also the 4-row shape: L=0 closure -3 %, and the un-pooling launches,
+// whose arg-max code words do not fit beside the form: in-loop spills, -25 %).
+static bool h2_use_m16(int mfma16, int th, int ntw, bool unpool) {
+    if (mfma16 >= 3) return true;
+    if (mfma16 == 2) return th == 8 || (th == 16 && ntw == 2 && !unpool);
+    return mfma16 == 1 && th == 8;
+}
 template <int TH, int BN, int NTW, int KC>
 static void launch_batch_cfg(const ConvBatch& b, int blocks, hipStream_t stream) {
     constexpr int lds = H2Cfg<TH, BN, NTW, KC>::LDS_BYTES;
     constexpr int nt = H2Cfg<TH, BN, NTW, KC>::NT;
     if constexpr (KC == 32 && NTW <= 2) {
-        if (b.mfma16 >= 2 || (b.mfma16 == 1 && TH == 8)) {
+        if (h2_use_m16(b.mfma16, TH, NTW, b.unpool != 0)) {
             if (b.unpool) hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, true, true, false>), dim3(blocks), dim3(nt), lds, stream, b);
             else hipLaunchKernelGGL((conv_h2_batch_kernel<TH, BN, NTW, KC, false, true, false>), dim3(blocks), dim3(nt), lds, stream, b);
             return;
@@ -1348,7 +1370,7 @@ static void launch_single_cfg(const ConvParams& p, int blocks, hipStream_t strea
     constexpr int lds = H2Cfg<TH, BN, NTW, KC>::LDS_BYTES;
     constexpr int nt = H2Cfg<TH, BN, NTW, KC>::NT;
     if constexpr (KC == 32 && NTW <= 2) {
-        if (p.mfma16 >= 2 || (p.mfma16 == 1 && TH == 8)) {
+        if (h2_use_m16(p.mfma16, TH, NTW, p.pcode_in != nullptr)) {
             if (p.pcode_in) hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW, KC, true, true>), dim3(blocks), dim3(nt), lds, stream, p);
             else hipLaunchKernelGGL((conv_h2_kernel<TH, BN, NTW, KC, false, true>), dim3(blocks), dim3(nt), lds, stream, p);
             return;
@@ -1396,7 +1418,7 @@ hipError_t launch_conv_h2_batch(const ConvBatch& b0, hipStream_t stream) {
     for (int i = 0; i < b.n; ++i) second = second || (b.img[i].in2 != nullptr);
     const int resident = 256 * ((!wide || shortk || th == 4) ? 2 : 1);
     b.total_tiles = blocks;
-    const bool m16 = b.mfma16 >= 2 || (b.mfma16 == 1 && th == 8);      // (the 16x16x32 form has no persistent build)
+    const bool m16 = h2_use_m16(b.mfma16, th, 2, b.unpool != 0) && !shortk && wide;      // (the 16x16x32 form has no persistent build)
     const bool pshape = !wide || shortk || (th == 16 && !b.wg256);
     b.persist = (b.persist && !second && b.Cin > 0 && blocks > resident && pshape && !m16) ? 1 : 0;
     if (b.persist) blocks = resident;

@@ -77,7 +77,8 @@ typedef struct nst_options {
     int h2_mfma16;        /* f16x2 convolutions with 32-channel chunks: v_mfma_f32_16x16x32_f16 instead of v_mfma_f32_32x32x16_f16
                              (same products, same accumulation chains per output; the chip clocks higher under it): 0 = never,
                              1 = on the 8-row x 128-channel shape (under-filled launches: +6 ... 11 % per launch),
-                             2 = on every 32-channel-chunk shape (slower on the others; kept for experiments);
+                             2 = also on the 16-row shape where the launch does not un-pool (no gain measured), 3 = on every
+                             32-channel-chunk shape (slower; both kept for experiments);
                              -1: env NST_H2_MFMA16, default 1 */
     int h2_wg256;         /* f16x2 convolutions, the 16x16-pixel x 128-channel tile: 1 = 256-thread workgroups, one wave per SIMD
                              with a 64 x 128 wave tile (accumulators in AGPRs), 0 = 512 threads with 64 x 64 wave tiles;

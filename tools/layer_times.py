@@ -14,6 +14,7 @@ for a in sys.argv[1:]:
         cur[k] = v if k == "conv_mode" else int(v)
 groups.append(cur)
 levels = int(os.environ.get("LEVELS", "3"))
+reps = int(os.environ.get("REPS", "30"))          # closures of the untimed rate (the chip is power-managed: use >= 200 for 1 % decisions)
 for opts in groups:
     eng, x, cfg, _ = bench.build_job(levels, 0, 0, **opts)
     cw, sw, tvw = cfg.content_weight, cfg.style_weight, cfg.tv_weight
@@ -23,10 +24,10 @@ for opts in groups:
     # untimed rate first (events cost a few %)
     t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
     t0.record()
-    for _ in range(30):
+    for _ in range(reps):
         eng.closure(x, cw, sw, tvw)
     t1.record(); torch.cuda.synchronize()
-    plain = t0.elapsed_time(t1) / 30
+    plain = t0.elapsed_time(t1) / reps
     eng.set_timing(2)
     eng.timing_totals(0, reset=True)
     for _ in range(8):
