@@ -408,9 +408,25 @@ def fx_lbfgs_config2geo_legacy(ref_mu, ref_nn, ref_nst, weights):
          moved=_moved(imgs, cl[0]), final=summarize(torch.from_numpy(imgs[-1][0]), k=1024, seed=66))
 
 
+def fx_config3_prefix(ref_mu, ref_nn, ref_nst, weights):
+    """BASELINE config 3's workload - the headline one: L=2 (1536x1024 + 768x512 + 384x256) - for as many iterations as
+    the CPU reference affords here (~10 s per closure on 8 cores): 16 Adam iterations (the image moves at every step) and
+    16 closures of L-BFGS as the reference constructs it.  Initial image: content top level blended with synthetic noise
+    (the reference's own content+noise init needs cv2).  Per-closure loss rows of all three levels, sampled pixels of
+    the images after step 1 and at the end."""
+    cl = _levels(1024, 1536, 3, seed=1)
+    sl = _levels(1024, 1536, 3, seed=2)
+    init = (0.7 * cl[0] + 0.3 * cpu_ref.synthetic_image(1024, 1536, seed=3)).astype(np.float32)
+    for opt, iters in (("adam", 16), ("lbfgs", 16)):
+        rows, imgs = _run_reference_process(ref_mu, ref_nst, cl, sl, init, opt, iters)
+        save(f"traj_{opt}_1024x1536_L2_16", rows=rows, steps=np.array([s for _, s in imgs], dtype=np.int64),
+             moved=_moved(imgs, init), final=summarize(torch.from_numpy(imgs[-1][0]), k=2048, seed=71),
+             after_1=summarize(torch.from_numpy(imgs[0][0]), k=2048, seed=72))
+
+
 ALL = {f.__name__[3:]: f for f in (fx_kat, fx_bicubic, fx_vgg, fx_closure_small, fx_closure_odd, fx_closure_L0,
                                    fx_adam_small, fx_lbfgs_small, fx_adam_L0, fx_adam_config2geo,
-                                   fx_lbfgs_config2geo_legacy, fx_lbfgs_config2)}
+                                   fx_lbfgs_config2geo_legacy, fx_lbfgs_config2, fx_config3_prefix)}
 
 
 def main():

@@ -200,3 +200,15 @@ def test_config2_geometry_prefixes(golden, vgg_weights):
         prev = img
     assert moved == list(fx["moved"][:2]) and list(fx["steps"][:2]) == [2, 4]
     np.testing.assert_allclose(np.array([r["rows"] for r in rec]), fx["rows"][:4], rtol=1e-4)
+
+
+def test_config3_workload_first_closure(golden, vgg_weights):
+    """The oracle at the headline workload's size (L=2: 1536x1024 + 768x512 + 384x256): the loss rows of the first closure
+    of the reference's Adam run (tests/golden/traj_adam_1024x1536_L2_16.npz; the 16-iteration runs are the GPU tests')."""
+    c, s = _levels(1024, 1536, 3, 1), _levels(1024, 1536, 3, 2)
+    init = (0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(1024, 1536, seed=3)).astype(np.float32)
+    fx = golden("traj_adam_1024x1536_L2_16")
+    rec = []
+    for img, step in cpu_ref.run_process(c, s, init, vgg_weights, "adam", 1, record=rec):
+        _check_summary(torch.from_numpy(img), fx, "after_1", rtol=0, atol=1e-5)
+    np.testing.assert_allclose(np.array([r["rows"] for r in rec]), fx["rows"][:1], rtol=2e-5)
