@@ -451,68 +451,82 @@ hipError_t launch_gram_partial(const float* f, size_t N, int C, int nsplit, cons
 }
 
 // G = (sum of the slabs, in slab order) / divisor; optional target: S = coef * (G - Gt) and the partial sums
-// of (G - Gt)^2.  A block owns 32 consecutive elements; its 8 lane groups each add every 8th slab, then the
-// 8 group sums are added in group order - a fixed order, so the result is reproducible.
+// of (G - Gt)^2.  A block owns 128 consecutive elements, four per lane (one 16-byte read per slab); its 8 lane groups each
+// add every 8th slab, then the 8 group sums are added in group order - a fixed order, so the result is reproducible.
+// (Blocks of 32 elements - 57 000 of them for an L=2 closure, each a handful of 128-byte reads, a barrier and a serial tail -
+// made this pass launch- and latency-bound: 0.129 ms for 273 MB.)
+constexpr int GF_EPB = NST_GRAM_FINISH_EPB;      // elements per block
 __device__ __forceinline__ void gram_finish_body(const float* __restrict__ part, int nslabs, int C, int ts, float divisor,
                                                  const float* __restrict__ target, float coef, float* __restrict__ gram_out,
                                                  float* __restrict__ S, unsigned short* __restrict__ S_bf,
                                                  unsigned* __restrict__ S_amax, double* __restrict__ mse_partial,
                                                  const unsigned bid) {
-    __shared__ float sh[8][32];
+    __shared__ f32x4 sh[8][32];
     __shared__ double shd[32];
     const size_t CC = (size_t)C * C;
     const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const size_t e = (size_t)bid * 32 + el;
-    const int i = (int)(e / C), j = (int)(e % C);
+    const size_t e0 = (size_t)bid * GF_EPB + (size_t)el * 4;      // this lane's first element (C % 4 == 0: one row)
+    const int i = (int)(e0 / C), j0 = (int)(e0 % C);
     // The tiled kernels compute the tiles on or above the diagonal only, and inside a diagonal tile the fp16-piece
     // kernel adds the two cross products of (i,j) and (j,i) in opposite orders: only elements with j >= i are read
-    // (coalesced) and each result is written to (i,j) AND (j,i), which makes G exactly symmetric.  A 32-element
-    // segment lies in one row (C % 32 == 0 for the tiled shapes); segments entirely below the diagonal do nothing.
+    // and each result is written to (i,j) AND (j,i), which makes G exactly symmetric.  With C a multiple of 128 a
+    // block's segment lies in one row; segments entirely below the diagonal do nothing.
     const bool tri = ts > 0;
-    if (tri && (int)((size_t)bid * 32 % C) + 31 < (int)((size_t)bid * 32 / C)) {
+    if (tri && C % GF_EPB == 0 && (int)((size_t)bid * GF_EPB % C) + GF_EPB - 1 < (int)((size_t)bid * GF_EPB / C)) {
         if (threadIdx.x == 0 && mse_partial) mse_partial[bid] = 0.0;
         return;
     }
-    const bool mine = e < CC && (!tri || j >= i);
-    float s = 0.f;
-    if (mine) {
-        // eight slab reads in flight per lane (the adds stay in slab order): this pass is latency-bound otherwise
+    // the lane reads its four elements when any of them is on or above the diagonal (the rest are discarded below)
+    const bool any = e0 < CC && (!tri || j0 + 3 >= i);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (!tri) {
+        // the generic shapes (unit-parity API: any channel count): element by element, bounds checked
+        for (int k = grp; k < nslabs; k += 8)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (e0 + q < CC) s[q] += part[(size_t)k * CC + e0 + q];
+    } else if (any) {
+        // eight slab reads in flight per lane (the adds stay in slab order)
         int k = grp;
         for (; k + 56 < nslabs; k += 64) {
-            float v[8];
+            f32x4 v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = part[(size_t)(k + 8 * j) * CC + e];
+            for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const f32x4*>(part + (size_t)(k + 8 * q) * CC + e0);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s += v[j];
+            for (int q = 0; q < 8; ++q) s += v[q];
         }
-        // the rest four at a time, slabs beyond the last read as +0 (x + 0 = x: same sum, same order) - with 25 slabs
-        // (C = 512) the loop above never runs, and one load in flight per lane left this pass latency-bound
+        // the rest four at a time, slabs beyond the last read as +0 (x + 0 = x: same sum, same order)
         for (; k < nslabs; k += 32) {
-            float v[4];
+            f32x4 v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (k + 8 * j < nslabs) ? part[(size_t)(k + 8 * j) * CC + e] : 0.f;
+            for (int q = 0; q < 4; ++q)
+                v[q] = (k + 8 * q < nslabs) ? *reinterpret_cast<const f32x4*>(part + (size_t)(k + 8 * q) * CC + e0) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s += v[j];
+            for (int q = 0; q < 4; ++q) s += v[q];
         }
     }
     sh[grp][el] = s;
     __syncthreads();
     if (grp == 0) {
-        float t = sh[0][el];
+        f32x4 t = sh[0][el];
 #pragma unroll
         for (int g = 1; g < 8; ++g) t += sh[g][el];
         double sq = 0.0;
         float sabs = 0.f;
-        if (mine) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t e = e0 + q;
+            const int i = (int)(e / C), j = (int)(e % C);      // (a tiled shape's four elements share the row)
+            if (!(e < CC && (!tri || j >= i))) continue;
             const bool both = tri && j > i;
             const size_t em = (size_t)j * C + i;      // the mirrored element
-            const float g = t / divisor;      // torch: gram /= ch*h*w
+            const float g = t[q] / divisor;      // torch: gram /= ch*h*w
             if (gram_out) { gram_out[e] = g; if (both) gram_out[em] = g; }
             if (target) {
                 const float d = g - target[e];
-                sq = (double)d * (double)d * (both ? 2.0 : 1.0);
+                sq += (double)d * (double)d * (both ? 2.0 : 1.0);
                 const float sv = coef * d;
-                sabs = fabsf(sv);
+                sabs = fmaxf(sabs, fabsf(sv));
                 if (S) { S[e] = sv; if (both) S[em] = sv; }
                 if (S_bf) {
                     // the same value cut into three bf16 pieces in conv_bf3's weight layout
@@ -565,7 +579,27 @@ __global__ __launch_bounds__(256) void gram_finish_batch_kernel(GramBatch b) {
                      it.S_bf, it.S_amax, it.mse_partial, blockIdx.x - (unsigned)(i ? b.it[i - 1].finish_end : 0));
 }
 
-int gram_finish_blocks(int C) { return (int)(((size_t)C * C + 31) / 32); }
+int gram_finish_blocks(int C) { return (int)(((size_t)C * C + GF_EPB - 1) / GF_EPB); }
+
+// Splits of an item inside a batch: the largest map of each channel count (the top pyramid level) takes gram_nsplit and
+// fills the chip by itself; a smaller map of the same channel count gets the same PIXELS per workgroup instead of the same
+// number of workgroups - its slabs (nsplit x C x C floats, written by the partial pass and read back by the finish pass)
+// shrink with its size.  L=2 closure: 273 -> 134 MB of slabs.  Never more than gram_nsplit(C, N): the partial buffers are
+// sized for that.
+static int gram_nsplit_in_batch(const GramBatch& b, int i) {
+    size_t nmax = b.it[i].N;
+    for (int k = 0; k < b.n; ++k)
+        if (b.it[k].C == b.it[i].C && b.it[k].N > nmax) nmax = b.it[k].N;
+    const int own = gram_nsplit(b.it[i].C, b.it[i].N);
+    const size_t scaled = ((size_t)gram_nsplit(b.it[i].C, nmax) * b.it[i].N + nmax - 1) / nmax;
+    int ns = (int)(scaled < 1 ? 1 : scaled);
+    if (ns > own) ns = own;
+    // (whole chunks per split, as gram_nsplit rounds)
+    const int kp = (gram_ts(b.it[i].C) == 128) ? 32 : 128;
+    const size_t chunks = (b.it[i].N + kp - 1) / kp;
+    const size_t cps = (chunks + ns - 1) / ns;
+    return (int)((chunks + cps - 1) / cps);
+}
 
 // Batched forms (fp16-piece kernels only: every item needs its absmax record, C = 64 or a multiple of 128, and its
 // own partial buffer of nsplit x C x C floats).  Fills nsplit / pix_per_split / the block prefixes.
@@ -583,7 +617,7 @@ hipError_t launch_gram_batch(const GramBatch& b0, hipStream_t stream) {
             const int kp = (ts == 128) ? 32 : 128;
             const int T = it.C / ts, pairs = T * (T + 1) / 2;
             const size_t chunks = (it.N + kp - 1) / kp;
-            it.nsplit = gram_nsplit(it.C, it.N);
+            it.nsplit = gram_nsplit_in_batch(b0, i);
             it.pix_per_split = ((chunks + it.nsplit - 1) / it.nsplit) * kp;
             // 32-bit buffer offsets inside ONE split (the map itself may be larger)
             if (it.pix_per_split * (size_t)it.C * 4 >= 0xFFFFFF00ull) return hipErrorInvalidValue;
@@ -601,7 +635,7 @@ hipError_t launch_gram_batch(const GramBatch& b0, hipStream_t stream) {
     GramBatch b = b0;
     for (int i = 0; i < b.n; ++i) {
         if (gram_ts(b.it[i].C) == 0) return hipErrorInvalidValue;
-        b.it[i].nsplit = gram_nsplit(b.it[i].C, b.it[i].N);          // = number of slabs
+        b.it[i].nsplit = gram_nsplit_in_batch(b0, i);               // = number of slabs
         b.it[i].finish_end = (i ? b.it[i - 1].finish_end : 0) + gram_finish_blocks(b.it[i].C);
         if (b.it[i].C % 32 != 0) b.it[i].S_bf = nullptr;
     }

@@ -212,6 +212,7 @@ struct GramItem {
 };
 struct GramBatch { GramItem it[NST_GRAM_BATCH_MAX]; int n; };
 hipError_t launch_gram_batch(const GramBatch& b, hipStream_t stream);
+#define NST_GRAM_FINISH_EPB 128      // elements of G a block of the finish pass owns (one partial sum of (G-Gt)^2 each)
 int gram_finish_blocks(int C);
 // S_amax (nullable): NST_AMAX_SLOTS words receiving the absmax of S (atomic max; zero them beforehand).
 hipError_t launch_gram_finish(const float* part, int nslabs, int C, float divisor, const float* target, float coef,

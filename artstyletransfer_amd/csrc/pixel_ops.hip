@@ -519,18 +519,18 @@ __global__ __launch_bounds__(256) void loss_rows_kernel(LossAssembly la) {
     v[0] = threadIdx.x < MSE_BLOCKS ? in.content_partial[threadIdx.x] : 0.0;
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        // C*C/32 partials: each thread adds its strided share in index order, then the fixed tree
-        const int nb = (in.style_c[k] * in.style_c[k] + 31) / 32;
-        double p[32];
+        // C*C / NST_GRAM_FINISH_EPB partials: each thread adds its strided share in index order, then the fixed tree
+        const int nb = (in.style_c[k] * in.style_c[k] + NST_GRAM_FINISH_EPB - 1) / NST_GRAM_FINISH_EPB;
+        double p[8];
 #pragma unroll
-        for (int j = 0; j < 32; ++j) {
+        for (int j = 0; j < 8; ++j) {
             const int b = threadIdx.x + j * 256;
             p[j] = b < nb ? in.style_partial[k][b] : 0.0;
         }
         double t = 0.0;
 #pragma unroll
-        for (int j = 0; j < 32; ++j) t += p[j];
-        for (int b = threadIdx.x + 32 * 256; b < nb; b += 256) t += in.style_partial[k][b];
+        for (int j = 0; j < 8; ++j) t += p[j];
+        for (int b = threadIdx.x + 8 * 256; b < nb; b += 256) t += in.style_partial[k][b];
         v[k + 1] = t;
     }
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
