@@ -106,6 +106,7 @@ struct nst_ctx {
     int tile_rows = 0;          // nst_options.h2_tile_rows
     int gram_overlap = 0;       // nst_options.gram_overlap
     int persist = 1;            // nst_options.h2_persist
+    int level_split = 0;        // nst_options.level_split
     hipStream_t side = nullptr; // the Gram launches of the shallow style layers run here, under the deeper forward convolutions
     hipEvent_t side_fork = nullptr, side_join = nullptr;
     hipEvent_t tail = nullptr;  // recorded after the last launch that touches context-owned memory: what
@@ -741,12 +742,13 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
     return NST_OK;
 }
 
+// `zero_mask`: the levels whose gradient this call clears when they are not in `level_mask` (levels another rank owns)
 int closure_batched(nst_ctx* ctx, const float* const* xi, float* const* gi, unsigned level_mask, float cw, float sw,
-                    float tvw, hipStream_t s) {
+                    float tvw, hipStream_t s, unsigned zero_mask = ~0u) {
     int lv[NST_MAX_LEVELS], n = 0;
     for (int i = 0; i < ctx->levels; ++i) {
         if ((level_mask >> i) & 1u) lv[n++] = i;
-        else HIPCHK(ctx, launch_zero(gi[i], (size_t)3 * ctx->lv[i].h * ctx->lv[i].w, s));
+        else if ((zero_mask >> i) & 1u) HIPCHK(ctx, launch_zero(gi[i], (size_t)3 * ctx->lv[i].h * ctx->lv[i].w, s));
     }
     if (n == 0) return NST_OK;
     // (not while a hipGraph is being captured or replayed: the closure then stays on one stream)
@@ -839,7 +841,7 @@ void nst_options_default(nst_options* o) {
     if (!o) return;
     o->struct_size = (int)sizeof(nst_options);
     o->conv_mode = -1; o->batched = -1; o->single_stream = -1; o->use_graph = -1; o->h2_band_rows = -1; o->lbfgs_gram = -1;
-    o->h2_mfma16 = -1; o->h2_wg256 = -1; o->h2_tile_rows = -1; o->gram_overlap = -1; o->h2_persist = -1;
+    o->h2_mfma16 = -1; o->h2_wg256 = -1; o->h2_tile_rows = -1; o->gram_overlap = -1; o->h2_persist = -1; o->level_split = -1;
 }
 
 int nst_ctx_create(int device, const float* const* weights, const float* const* biases, nst_ctx** out) {
@@ -889,6 +891,7 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
     ctx->wg256 = (opts.h2_wg256 >= 0 ? opts.h2_wg256 : env_flag("NST_H2_WG256", 0)) ? 1 : 0;
     ctx->tile_rows = opts.h2_tile_rows >= 0 ? opts.h2_tile_rows : env_flag("NST_H2_TILE_ROWS", 0);
     ctx->persist = (opts.h2_persist >= 0 ? opts.h2_persist : env_flag("NST_H2_PERSIST", 0)) ? 1 : 0;
+    ctx->level_split = (opts.level_split >= 0 ? opts.level_split : env_flag("NST_LEVEL_SPLIT", 0)) ? 1 : 0;
     ctx->gram_overlap = (opts.gram_overlap >= 0 ? opts.gram_overlap : env_flag("NST_GRAM_OVERLAP", 0)) ? 1 : 0;
     if (ctx->use_graph && hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "stream creation failed"; return bail(NST_E_HIP); }
     if (e != hipSuccess) { ctx->err = std::string("kernel attribute setup: ") + hipGetErrorString(e); return bail(NST_E_HIP); }
@@ -953,7 +956,8 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
             if (hipMemcpy(ctx->wd_h2[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
         }
     }
-    if (ctx->gram_overlap && ctx->conv_mode == 2 &&
+    if (ctx->level_split) ctx->gram_overlap = 0;      // (one side stream: the two experiments exclude each other)
+    if ((ctx->gram_overlap || ctx->level_split) && ctx->conv_mode == 2 &&
         (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
          hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming) != hipSuccess ||
          hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming) != hipSuccess)) {
@@ -1162,7 +1166,20 @@ static int closure_record(nst_ctx* ctx, const float* x, float cw, float sw, floa
     }
     const bool batch = batch_eligible(ctx);
     if (batch) {
-        NSTCHK(closure_batched(ctx, xi, gi, level_mask, cw, sw, tvw, main));
+        const unsigned top = level_mask & 1u, rest = level_mask & ~1u;
+        if (ctx->level_split && ctx->side && !ctx->use_graph && top && rest) {
+            // nst_options.level_split: the top level's chain on the caller's stream, the lower levels' (batched among
+            // themselves) on the side stream - two chains of unequal size whose launch ramps, tails and epilogue bursts can
+            // fill one another, as two jobs on one GPU do.  Same kernels on the same tiles: bitwise the same.
+            HIPCHK(ctx, hipEventRecord(ctx->side_fork, main));
+            HIPCHK(ctx, hipStreamWaitEvent(ctx->side, ctx->side_fork, 0));
+            NSTCHK(closure_batched(ctx, xi, gi, top, cw, sw, tvw, main, 1u));
+            NSTCHK(closure_batched(ctx, xi, gi, rest, cw, sw, tvw, ctx->side, ~1u));
+            HIPCHK(ctx, hipEventRecord(ctx->side_join, ctx->side));
+            HIPCHK(ctx, hipStreamWaitEvent(main, ctx->side_join, 0));
+        } else {
+            NSTCHK(closure_batched(ctx, xi, gi, level_mask, cw, sw, tvw, main));
+        }
     }
     const bool multi = !batch && !ctx->single_stream && ctx->levels > 1;
     if (multi) {

@@ -92,6 +92,9 @@ typedef struct nst_options {
                              walks its share of the tiles with the K pipeline chained from one tile into the next);
                              0 = one workgroup per tile; -1: env NST_H2_PERSIST, default 0 (measured: the chained form's extra scalar state
                              costs more than the hidden prologues gain) */
+    int level_split;      /* f16x2 batched closure: 1 = the top pyramid level's chain on the caller's stream and the lower levels'
+                             chain on a side stream of the context, joined before the gradients are merged; 0 = one launch per
+                             layer over all levels; -1: env NST_LEVEL_SPLIT, default 0 */
 } nst_options;
 void nst_options_default(nst_options* opts);
 int nst_ctx_create_ex(int device, const float* const* weights, const float* const* biases, const nst_options* opts,
