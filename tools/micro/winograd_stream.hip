@@ -9,6 +9,8 @@
 //   W  A fragments from LDS, B fragments by global_load_dwordx4 from a 12.6 MB weight image (4 output-channel tiles x 16
 //      chunks x 3 ky stages x 64 KB, every workgroup walking the same sequence), loaded one stage ahead
 //   W0 the same with every workgroup and stage reading the SAME 64 KB (L2-hit upper bound of the load path)
+//   D  the direct convolution's sharing: the four waves along the pixel dimension read the same fragments (16 KB per stage,
+//      9.4 MB image): the shipped kernel with its weight slices fetched L2/L1 -> registers instead of staged through LDS
 // Random fp16 operands.  Prints TFLOP/s of executed f16 MFMA work and the B bytes per second of W.
 //   hipcc -O3 --offload-arch=gfx950 tools/micro/winograd_stream.hip -o /tmp/ws && /tmp/ws
 #include <hip/hip_runtime.h>
@@ -69,8 +71,11 @@ __global__ __launch_bounds__(512, 2) void shape_a(const f16x8* __restrict__ ops,
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
-// W: B fragments straight from the weight image.  SAME: every stage reads stage 0 of tile 0.
-template <bool SAME>
+// W: B fragments straight from the weight image.  MODE 0: every wave its own slice (Winograd: 48 stages x 64 KB per output-channel tile);
+// MODE 1: every stage reads stage 0 of tile 0; MODE 2: the DIRECT convolution's sharing - the four waves along the pixel dimension read
+// the SAME fragments (144 stages x 16 KB per output-channel tile = the 9.4 MB of a 512 -> 512 layer), i.e. the shipped kernel with its
+// weight slices fetched L2/L1 -> registers instead of staged through LDS.
+template <int MODE>
 __global__ __launch_bounds__(512, 2) void shape_w(const f16x8* __restrict__ ops, const f16x8* __restrict__ wimg, float* __restrict__ out,
                                                  int iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -78,6 +83,10 @@ __global__ __launch_bounds__(512, 2) void shape_w(const f16x8* __restrict__ ops,
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int base = (wave * 32 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+    constexpr bool SAME = (MODE == 1);
+    constexpr int NST = (MODE == 2) ? 144 : STAGES;
+    constexpr int SLOTS = (MODE == 2) ? 2 : 8;
+    const int slot = (MODE == 2) ? (wave >> 2) : wave;
     const int ct = SAME ? 0 : (int)(blockIdx.x & 3);
     f32x16 am[4], ax[4];
     for (int c = 0; c < 4; ++c)
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void shape_w(const f16x8* __restrict__ ops,
             for (int p = 0; p < 2; ++p) a[set][t][p] = ld(lds, o + t * 4608 + p * 64);
     };
     auto req_b = [&](int set, int stage) {
-        const size_t u0 = (((size_t)(ct * STAGES + (SAME ? 0 : stage)) * 8 + wave) * 8) * 64 + lane;
+        const size_t u0 = (((size_t)(ct * NST + (SAME ? 0 : stage)) * SLOTS + slot) * 8) * 64 + lane;
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
@@ -116,7 +125,7 @@ __global__ __launch_bounds__(512, 2) void shape_w(const f16x8* __restrict__ ops,
         // two stages per trip so that the B register sets are compile-time constants
         {
             const int o = base + (it & 7) * 576;
-            const int nx = (stage + 1 == STAGES) ? 0 : stage + 1;
+            const int nx = (stage + 1 == NST) ? 0 : stage + 1;
             req_b(1, nx);                  // next stage's weights, a whole stage ahead
             req_a(1, o + 32);
             mul(0, 0, 0);
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(512, 2) void shape_w(const f16x8* __restrict__ ops,
         }
         {
             const int o = base + ((it + 1) & 7) * 576;
-            const int nx = (stage + 1 == STAGES) ? 0 : stage + 1;
+            const int nx = (stage + 1 == NST) ? 0 : stage + 1;
             req_b(0, nx);
             req_a(1, o + 32);
             mul(0, 1, 0);
@@ -171,18 +180,21 @@ int main() {
     (void)hipMemcpy(ops, h.data(), LDS_BYTES, hipMemcpyHostToDevice);
     (void)hipMemcpy(wimg, hw.data(), W_UNITS * 16, hipMemcpyHostToDevice);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&shape_a), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 32768);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&shape_w<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 32768);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&shape_w<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 32768);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&shape_w<0>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 32768);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&shape_w<1>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 32768);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&shape_w<2>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + 32768);
     const int blocks = 256;
     const double flops = (double)blocks * 8 * iters * 24 * 2.0 * 32 * 32 * 16;
     for (int rep = 0; rep < 2; ++rep) {
         double msw = 0.0;
         const double fa = timed([&](int d) { hipLaunchKernelGGL(shape_a, dim3(blocks), dim3(512), LDS_BYTES + 32768, 0, ops, out, iters / d); }, flops);
-        const double fw = timed([&](int d) { hipLaunchKernelGGL(shape_w<false>, dim3(blocks), dim3(512), LDS_BYTES + 32768, 0, ops, wimg, out, iters / d); },
+        const double fw = timed([&](int d) { hipLaunchKernelGGL(shape_w<0>, dim3(blocks), dim3(512), LDS_BYTES + 32768, 0, ops, wimg, out, iters / d); },
                                 flops, &msw);
-        const double f0 = timed([&](int d) { hipLaunchKernelGGL(shape_w<true>, dim3(blocks), dim3(512), LDS_BYTES + 32768, 0, ops, wimg, out, iters / d); }, flops);
+        const double f0 = timed([&](int d) { hipLaunchKernelGGL(shape_w<1>, dim3(blocks), dim3(512), LDS_BYTES + 32768, 0, ops, wimg, out, iters / d); }, flops);
+        const double f2 = timed([&](int d) { hipLaunchKernelGGL(shape_w<2>, dim3(blocks), dim3(512), LDS_BYTES + 32768, 0, ops, wimg, out, iters / d); }, flops);
         printf("A both operands from LDS: %.0f TFLOP/s | W B fragments from a 12.6 MB image in L2: %.0f TFLOP/s (%.1f TB/s of B) | "
-               "W0 B fragments all from one 64 KB block: %.0f TFLOP/s\n", fa, fw, (double)blocks * iters * 65536.0 / (msw * 1e-3) / 1e12, f0);
+               "W0 B fragments all from one 64 KB block: %.0f TFLOP/s | D direct-conv sharing (4 waves read the same fragments, 9.4 MB image): %.0f TFLOP/s\n",
+               fa, fw, (double)blocks * iters * 65536.0 / (msw * 1e-3) / 1e12, f0, f2);
     }
     return 0;
 }
