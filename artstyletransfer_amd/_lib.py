@@ -39,7 +39,7 @@ class Options(C.Structure):
     """nst_options: -1 = take the environment variable (read once at context creation), else the default."""
     _fields_ = [("struct_size", C.c_int), ("conv_mode", C.c_int), ("batched", C.c_int), ("single_stream", C.c_int),
                 ("use_graph", C.c_int), ("h2_band_rows", C.c_int), ("lbfgs_gram", C.c_int), ("h2_mfma16", C.c_int),
-                ("h2_wg256", C.c_int), ("h2_tile_rows", C.c_int), ("gram_overlap", C.c_int), ("h2_persist", C.c_int), ("level_split", C.c_int)]
+                ("h2_wg256", C.c_int), ("h2_tile_rows", C.c_int), ("gram_overlap", C.c_int), ("h2_persist", C.c_int), ("level_split", C.c_int), ("h2_winograd", C.c_int)]
 
 
 # name -> (restype, argtypes); every symbol include/nst_hip.h declares

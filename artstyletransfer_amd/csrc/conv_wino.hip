@@ -1,0 +1,301 @@
+// conv_wino.hip - the 3x3 convolution forward (bias + ReLU + ReLU bit mask) as a 1-D Winograd F(2,3) along x on the fp16
+// matrix pipe, in the f16x2 arithmetic of conv_h2.hip: 1.5x fewer MFMAs per output.  EXPERIMENT behind
+// nst_options.h2_winograd (forward launches with Cin >= 128, Cout a multiple of 128 and no pooling behind them).
+//
+// For an output pair (x = 2p, 2p + 1) of a row and the input columns d0..d3 = x - 1 .. x + 2 (one tap row ky):
+//     t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3                    (input transform, fp32, before the cut)
+//     u0 = g0, u1 = (g0 + g1 + g2) / 2, u2 = (g0 - g1 + g2) / 2, u3 = g2        (filter transform, host, fp64)
+//     m_xi = sum over ky and input channels of t_xi u_xi;   y(2p) = m0 + m1 + m2,   y(2p + 1) = m1 - m2 - m3
+// so a stage (ky, 32 input channels) is four GEMMs [pairs x 32] x [32 x Cout], one per xi, over HALF as many rows as
+// there are pixels: 12 of them per chunk instead of 9 over all pixels.
+//
+// Workgroup: 512 threads, 8 rows x 16 columns of pixels = 64 pairs, 128 output channels.  Wave w owns xi = w & 3 and the
+// output-channel half wn = w >> 2: a 64 x 64 wave tile of m_xi on v_mfma_f32_32x32x16_f16 with main and cross
+// accumulators, exactly conv_h2.hip's products.  Its A fragments (the transformed patch rows of its xi) come from LDS;
+// its B fragments belong to a weight slice no other wave shares beyond the other channel half, so they are loaded
+// L2 -> registers in fragment order (host layout below), two k-steps ahead; LDS holds only the double-buffered patch
+// and there is ONE barrier per chunk (3 stages).  tools/micro/winograd_stream.hip measured this operand stream at 0.87
+// of the both-from-LDS stream's MFMA rate.  The four xi accumulators of a pair live in four waves: the epilogue meets
+// them in LDS (one channel half at a time), applies the output transform, bias and ReLU, and stores 16-byte pieces.
+#include <hip/hip_runtime.h>
+
+#include "nst_kernels.h"
+
+namespace nst {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int W_TH = 8, W_TW = 16, W_PAIRS = 8, W_PH = W_TH + 2;
+constexpr int W_ROWB = 144;                              // 32 channels x 2 pieces x 2 B + 16 B pad
+constexpr int W_PROWB = 4 * W_PAIRS * W_ROWB + 128;      // a patch row: [xi][pair] entries; + 128 B: rows y and y + 1 of a fragment
+                                                         // (16 lanes = 2 rows x 8 pairs) land on complementary 16-byte slots
+constexpr int W_A_BYTES = W_PH * W_PROWB;
+constexpr int W_E_BYTES = 4 * 64 * 64 * 4;               // epilogue: m[xi][pair row][64 channels] fp32
+constexpr int W_BITS_OFF = W_E_BYTES;                    // + 128 pixels x 2 words
+constexpr int W_LDS = 2 * W_A_BYTES;
+static_assert(W_E_BYTES + 128 * 2 * 4 <= W_LDS, "the epilogue reuses the patch buffers");
+constexpr float LO_UP = 2048.f, LO_DOWN = 1.f / 2048.f;
+
+__device__ __forceinline__ void cut2x4(const f32x4 v, const float s, u32x2& hi, u32x2& lo) {
+    const f32x2 x01 = {v[0] * s, v[1] * s}, x23 = {v[2] * s, v[3] * s};
+    const f16x2 h01 = __builtin_convertvector(x01, f16x2), h23 = __builtin_convertvector(x23, f16x2);
+    const f32x2 b01 = __builtin_convertvector(h01, f32x2), b23 = __builtin_convertvector(h23, f32x2);
+    const f32x2 r01 = (x01 - b01) * LO_UP, r23 = (x23 - b23) * LO_UP;
+    const f16x2 l01 = __builtin_convertvector(r01, f16x2), l23 = __builtin_convertvector(r23, f16x2);
+    hi = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+    lo = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+}
+
+__device__ __forceinline__ int xcd_order(const int b, const int grid) {
+    const int x = b & 7, k = b >> 3;
+    const int q = grid >> 3, r = grid & 7;
+    return x * q + (x < r ? x : r) + k;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(512, 2) void conv_wino_fwd_batch_kernel(ConvBatch b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xi = wave & 3, wn = wave >> 2;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // tile of this workgroup
+    const int n_ct = b.Cout >> 7;
+    const int t = xcd_order((int)blockIdx.x, (int)gridDim.x);
+    const int sp_all = t / n_ct, ct = t - sp_all * n_ct;
+    int ii = 0;
+    while (ii + 1 < b.n && sp_all >= b.img[ii].tile_end) ++ii;
+    const ConvImage& im = b.img[ii];
+    const int sp = sp_all - (ii ? b.img[ii - 1].tile_end : 0);
+    const int H = im.H, W = im.W, Cin = b.Cin, Cout = b.Cout;
+    const int ty = sp / im.tiles_x, tx = sp - ty * im.tiles_x;
+    const int y0 = ty * W_TH, x0 = tx * W_TW, n0 = ct * 128;
+    const int nch = Cin >> 5;
+
+    // operand scale: the transformed values reach twice the tensor maximum, so one binade below conv_h2's scale
+    float sa, ia;
+    {
+        unsigned m = im.amax_in[lane];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned o = (unsigned)__shfl_xor((int)m, off);
+            m = o > m ? o : m;
+        }
+        int e = (int)((m >> 23) & 0xFFu);
+        e = e < 32 ? 32 : (e > 250 ? 250 : e);
+        sa = __uint_as_float((unsigned)(267 - e) << 23);      // 2^(13 - (e - 127))
+        ia = __uint_as_float((unsigned)(e - 13) << 23);
+    }
+    const float inv = ia * b.wt_wino_inv;
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(im.in), 0, (unsigned)((size_t)H * W * Cin * 4), 0x00020000);
+    const f16x8* __restrict__ wimg = reinterpret_cast<const f16x8*>(b.wt_wino);
+
+    f32x16 accm[2][2], accx[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accx[a][c][r] = 0.f; }
+
+    // ---- patch staging: task u = (patch row, pair, channel quad): four pixels in, four transformed units out
+    auto task_voff = [&](int u, int j) -> unsigned {
+        const int row = u >> 6, pair = (u >> 3) & 7, quad = u & 7;
+        const int gy = y0 - 1 + row, gx = x0 + 2 * pair - 1 + j;
+        const bool ok = (u < W_PH * 64) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+        return ok ? ((unsigned)(gy * W + gx) * (unsigned)Cin + (unsigned)quad * 4u) * 4u : 0xFFFFFF00u;
+    };
+    auto task_load = [&](f32x4 (&d)[4], int u, int chunk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, task_voff(u, j), chunk * 128, 0));
+    };
+    auto task_store = [&](const f32x4 (&d)[4], int u, unsigned char* buf) {
+        if (u >= W_PH * 64) return;
+        const int row = u >> 6, pair = (u >> 3) & 7, quad = u & 7;
+        const f32x4 tt[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
+        unsigned char* base = buf + row * W_PROWB + pair * W_ROWB + quad * 8;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            u32x2 hi, lo;
+            cut2x4(tt[x], sa, hi, lo);
+            *reinterpret_cast<u32x2*>(base + x * W_PAIRS * W_ROWB) = hi;
+            *reinterpret_cast<u32x2*>(base + x * W_PAIRS * W_ROWB + 64) = lo;
+        }
+    };
+
+    // ---- fragments
+    // A: lane (r = l31, h = half) holds A[pair row r of the m tile][k = 8 h + j]; pair row = 4 image rows x 8 pairs
+    const int a_base = ((l31 >> 3)) * W_PROWB + (xi * W_PAIRS + (l31 & 7)) * W_ROWB + half * 16;
+    struct AF { f16x8 v[2][2]; };       // [m tile][piece]
+    auto read_a = [&](AF& f, const unsigned char* buf, int ky, int ks) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                f.v[mt][s] = *reinterpret_cast<const f16x8*>(buf + a_base + (mt * 4 + ky) * W_PROWB + s * 64 + ks * 32);
+    };
+    // B: 16-byte units [ct][chunk][ky][wave][ks][nt][piece][lane]
+    struct BF { f16x8 v[2][2]; };       // [n tile][piece]
+    auto load_b = [&](BF& f, int chunk, int ky, int ks) {
+        const size_t u0 = ((((size_t)(ct * nch + chunk) * 3 + ky) * 8 + wave) * 2 + ks) * 4 * 64 + lane;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) f.v[nt][s] = wimg[u0 + (size_t)(nt * 2 + s) * 64];
+    };
+    auto multiply = [&](const AF& a, const BF& w) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[mt][1], w.v[nt][0], accx[mt][nt], 0, 0, 0);
+                accm[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[mt][0], w.v[nt][0], accm[mt][nt], 0, 0, 0);
+                accx[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a.v[mt][0], w.v[nt][1], accx[mt][nt], 0, 0, 0);
+            }
+    };
+
+    // ---- prologue: chunk 0 into buffer 0, the first two k-steps' weights on their way
+    f32x4 d[4], d2[4];      // staging of the two patch tasks of a thread (the second exists for waves 0 and 1 only)
+    BF B[3];
+    AF A[2];
+    {
+        task_load(d, tid, 0);
+        load_b(B[0], 0, 0, 0);
+        load_b(B[1], 0, 0, 1);
+        task_store(d, tid, smem);
+        if (tid < W_PH * 64 - 512) {
+            task_load(d, tid + 512, 0);
+            task_store(d, tid + 512, smem);
+        }
+    }
+    __syncthreads();
+    read_a(A[0], smem, 0, 0);
+
+    // ---- K loop: per chunk 3 stages (ky) of 2 k-steps; k-step q of the chunk multiplies B[q % 3] and loads the weights of
+    // k-step q + 2 into B[(q + 2) % 3]; the next chunk's patch is loaded in two goes and cut into the other buffer
+    for (int c = 0; c < nch; ++c) {
+        const unsigned char* cur = smem + (c & 1) * W_A_BYTES;
+        unsigned char* nxt = smem + ((c + 1) & 1) * W_A_BYTES;
+        const int cn = (c + 1 < nch) ? c + 1 : c;          // (last chunk: a dummy re-load, nobody reads the result)
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            // weights two k-steps ahead
+            {
+                const int q2 = q + 2;
+                if (q2 < 6) load_b(B[q2 % 3], c, q2 >> 1, q2 & 1);
+                else load_b(B[q2 % 3], cn, (q2 - 6) >> 1, (q2 - 6) & 1);
+            }
+            if (q == 0) task_load(d, tid, cn);
+            if (q == 1 && tid < W_PH * 64 - 512) task_load(d2, tid + 512, cn);
+            // next k-step's A fragments
+            if (q + 1 < 6) read_a(A[(q + 1) & 1], cur, (q + 1) >> 1, (q + 1) & 1);
+            multiply(A[q & 1], B[q % 3]);
+            if (q == 4) task_store(d, tid, nxt);
+            if (q == 5 && tid < W_PH * 64 - 512) task_store(d2, tid + 512, nxt);
+        }
+        __syncthreads();
+        if (c + 1 < nch) read_a(A[0], nxt, 0, 0);
+    }
+
+    // ---- epilogue: the four xi accumulators of every pair meet in LDS, one output-channel half at a time
+    float* E = reinterpret_cast<float*>(smem);                               // [xi][pair row 64][64]
+    unsigned* WB = reinterpret_cast<unsigned*>(smem + W_BITS_OFF);           // [pixel 128][2 words]
+    const int words = Cout >> 5;
+    float amax = 0.f;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (wn == pass) {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;      // row of the 32-row tile
+                        E[(xi * 64 + mt * 32 + m) * 64 + nt * 32 + l31] = fmaf(accx[mt][nt][r], LO_DOWN, accm[mt][nt][r]) * inv;
+                    }
+        }
+        if (tid < 256) WB[tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int task = tid + k * 512;            // (pair row, channel quad)
+            const int pr = task >> 4, cq = task & 15;
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(E + (0 * 64 + pr) * 64 + cq * 4);
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(E + (1 * 64 + pr) * 64 + cq * 4);
+            const f32x4 m2 = *reinterpret_cast<const f32x4*>(E + (2 * 64 + pr) * 64 + cq * 4);
+            const f32x4 m3 = *reinterpret_cast<const f32x4*>(E + (3 * 64 + pr) * 64 + cq * 4);
+            const int co = n0 + pass * 64 + cq * 4;
+            const f32x4 bv = b.bias ? *reinterpret_cast<const f32x4*>(b.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 ya = m0 + m1 + m2 + bv, yb = m1 - m2 - m3 + bv;
+            unsigned na = 0u, nb = 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (b.relu) { ya[e] = fmaxf(ya[e], 0.f); yb[e] = fmaxf(yb[e], 0.f); }
+                na |= (ya[e] > 0.f ? 1u : 0u) << e;
+                nb |= (yb[e] > 0.f ? 1u : 0u) << e;
+                amax = fmaxf(amax, fmaxf(fabsf(ya[e]), fabsf(yb[e])));
+            }
+            const int yy = pr >> 3, p = pr & 7;
+            const int gy = y0 + yy, gx = x0 + 2 * p;
+            if (gy < H && gx < W) *reinterpret_cast<f32x4*>(im.out + ((size_t)gy * W + gx) * Cout + co) = ya;
+            if (gy < H && gx + 1 < W) *reinterpret_cast<f32x4*>(im.out + ((size_t)gy * W + gx + 1) * Cout + co) = yb;
+            if (im.bits_out) {
+                const int pix = yy * 16 + 2 * p, w = cq >> 3, sh = (cq & 7) * 4;
+                atomicOr(&WB[pix * 2 + w], na << sh);
+                atomicOr(&WB[(pix + 1) * 2 + w], nb << sh);
+            }
+        }
+        __syncthreads();
+        if (im.bits_out && tid < 256) {
+            const int pix = tid >> 1, w = tid & 1;
+            const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
+            if (gy < H && gx < W) im.bits_out[((size_t)gy * W + gx) * words + (n0 >> 5) + pass * 2 + w] = WB[tid];
+        }
+        __syncthreads();
+    }
+    if (im.amax_out) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        if (lane == 0) atomicMax(im.amax_out + ((blockIdx.x * 8 + wave) & (NST_AMAX_SLOTS - 1)), __float_as_uint(amax));
+    }
+}
+
+hipError_t conv_wino_init_device() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_fwd_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+}
+
+bool conv_wino_eligible(const ConvBatch& b) {
+    if (!b.wt_wino || b.Cin < 128 || b.Cin % 64 != 0 || b.Cout % 128 != 0 || b.unpool || b.Cin2 != 0) return false;
+    for (int i = 0; i < b.n; ++i) {
+        const ConvImage& im = b.img[i];
+        if (im.in2 || im.addend || im.mask || im.bits_in || im.pool_out || im.pcode_out || !im.amax_in) return false;
+        if ((size_t)im.H * im.W * (b.Cin > b.Cout ? b.Cin : b.Cout) * 4 >= 0xFFFFFF00ull) return false;
+    }
+    return true;
+}
+
+hipError_t launch_conv_wino_batch(const ConvBatch& b0, hipStream_t stream) {
+    if (b0.n < 1 || b0.n > 8 || !conv_wino_eligible(b0)) return hipErrorInvalidValue;
+    ConvBatch b = b0;
+    int tiles = 0;
+    for (int i = 0; i < b.n; ++i) {
+        b.img[i].tiles_x = (b.img[i].W + W_TW - 1) / W_TW;
+        tiles += b.img[i].tiles_x * ((b.img[i].H + W_TH - 1) / W_TH);
+        b.img[i].tile_end = tiles;
+    }
+    hipLaunchKernelGGL(conv_wino_fwd_batch_kernel, dim3(tiles * (b.Cout / 128)), dim3(512), W_LDS, stream, b);
+    return hipGetLastError();
+}
+
+}  // namespace nst

@@ -92,6 +92,9 @@ struct nst_ctx {
     float* wd[NL] = {};
     void* wf_bf[NL] = {};       // the same weights cut into 3 bf16 pieces (conv_bf3.hip layout)
     void* wd_bf[NL] = {};
+    void* wf_wino[NL] = {};     // conv_wino.hip's transformed forward weights (nst_options.h2_winograd), true = pieces * wf_wino_inv
+    float wf_wino_inv[NL] = {};
+    int winograd = 0;           // nst_options.h2_winograd
     void* wf_h2[NL] = {};       // ... cut into 2 scaled fp16 pieces (conv_h2.hip layout), true = pieces * w*_h2_inv
     void* wd_h2[NL] = {};
     float wf_h2_inv[NL] = {};
@@ -284,6 +287,51 @@ void make_h2(const float* w, int taps, int rows, int K, std::vector<uint16_t>& o
                 const size_t base = (((size_t)t * rows + r) * nch + k / kc) * 2 * kc + (k % kc);
                 out[base] = uh; out[base + kc] = ul;
             }
+}
+
+// w: [9 taps = ky*3 + kx][rows = Cout][K = Cin] fp32  ->  the 1-D Winograd F(2,3) weights of conv_wino.hip: for every ky the
+// four transformed taps u0 = g0, u1 = (g0 + g1 + g2)/2, u2 = (g0 - g1 + g2)/2, u3 = g2 (fp64), scaled by the power of two that
+// brings the largest |u| into [2^14, 2^15), cut into two fp16 pieces, in MFMA FRAGMENT order - 16-byte units
+// [Cout/128][K/32][ky][wave = xi + 4 wn][k-step][n tile][piece][lane]: lane (r = lane & 31, h = lane >> 5) holds the 8 input
+// channels chunk*32 + kstep*16 + 8 h .. + 7 of output channel ct*128 + wn*64 + ntile*32 + r.
+void make_wino(const float* w, int rows, int K, std::vector<uint16_t>& out, float* inv) {
+    const int nct = rows / 128, nch = K / 32;
+    auto u_of = [&](int ky, int x, int o, int c) -> double {
+        const double g0 = w[((size_t)(ky * 3 + 0) * rows + o) * K + c], g1 = w[((size_t)(ky * 3 + 1) * rows + o) * K + c],
+                     g2 = w[((size_t)(ky * 3 + 2) * rows + o) * K + c];
+        return x == 0 ? g0 : x == 1 ? 0.5 * (g0 + g1 + g2) : x == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+    };
+    double mx = 0.0;
+    for (int ky = 0; ky < 3; ++ky)
+        for (int x = 0; x < 4; ++x)
+            for (int o = 0; o < rows; ++o)
+                for (int c = 0; c < K; ++c) mx = std::max(mx, std::fabs(u_of(ky, x, o, c)));
+    int ex = 0;
+    if (mx > 0.0) (void)std::frexp(mx, &ex);
+    const float s = std::ldexp(1.f, 15 - ex);
+    *inv = std::ldexp(1.f, ex - 15);
+    out.assign((size_t)nct * nch * 3 * 8 * 2 * 2 * 2 * 64 * 8, 0);
+    for (int ct = 0; ct < nct; ++ct)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int ky = 0; ky < 3; ++ky)
+                for (int wave = 0; wave < 8; ++wave)
+                    for (int ks = 0; ks < 2; ++ks)
+                        for (int nt = 0; nt < 2; ++nt)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int x = wave & 3, wn = wave >> 2, r = lane & 31, h = lane >> 5;
+                                const int o = ct * 128 + wn * 64 + nt * 32 + r;
+                                const size_t unit = ((((((size_t)(ct * nch + ch) * 3 + ky) * 8 + wave) * 2 + ks) * 2 + nt) * 2) * 64 + lane;
+                                for (int j = 0; j < 8; ++j) {
+                                    const int c = ch * 32 + ks * 16 + 8 * h + j;
+                                    const float v = (float)u_of(ky, x, o, c) * s;
+                                    const _Float16 hi = (_Float16)v;
+                                    const _Float16 lo = (_Float16)((v - (float)hi) * 2048.f);
+                                    uint16_t uh, ul;
+                                    std::memcpy(&uh, &hi, 2); std::memcpy(&ul, &lo, 2);
+                                    out[unit * 8 + j] = uh;                      // piece 0
+                                    out[(unit + 64) * 8 + j] = ul;               // piece 1
+                                }
+                            }
 }
 
 int pool_index_after(int l) {
@@ -557,6 +605,7 @@ int batched_forward(nst_ctx* ctx, const float* const* xi, const int* lv, int n, 
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wf_bf[l]; b.bias = ctx->bias[l]; b.Cin = kCin[l]; b.Cout = kCout[l]; b.relu = 1;
         b.wt_h2 = ctx->wf_h2[l]; b.wt_h2_inv = ctx->wf_h2_inv[l]; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows; b.persist = ctx->persist;
+        b.wt_wino = ctx->wf_wino[l]; b.wt_wino_inv = ctx->wf_wino_inv[l];
         double flops = 0;
         for (int k = 0; k < n; ++k) {
             ActSet& a = ctx->lv[lv[k]].acts;
@@ -573,7 +622,8 @@ int batched_forward(nst_ctx* ctx, const float* const* xi, const int* lv, int n, 
         }
         {
             Timer t(ctx, s, K_CONV3, flops, b.img[0].H, b.img[0].W, b.Cin, b.Cout, 9, l);
-            HIPCHK(ctx, h2 ? launch_conv_h2_batch(b, s) : launch_conv_bf3_batch(b, s));
+            if (h2 && b.wt_wino && conv_wino_eligible(b)) HIPCHK(ctx, launch_conv_wino_batch(b, s));
+            else HIPCHK(ctx, h2 ? launch_conv_h2_batch(b, s) : launch_conv_bf3_batch(b, s));
         }
         if (l == 4 && fork_sw >= 0.f && ctx->side) {
             HIPCHK(ctx, hipEventRecord(ctx->side_fork, s));
@@ -841,7 +891,7 @@ void nst_options_default(nst_options* o) {
     if (!o) return;
     o->struct_size = (int)sizeof(nst_options);
     o->conv_mode = -1; o->batched = -1; o->single_stream = -1; o->use_graph = -1; o->h2_band_rows = -1; o->lbfgs_gram = -1;
-    o->h2_mfma16 = -1; o->h2_wg256 = -1; o->h2_tile_rows = -1; o->gram_overlap = -1; o->h2_persist = -1; o->level_split = -1;
+    o->h2_mfma16 = -1; o->h2_wg256 = -1; o->h2_tile_rows = -1; o->gram_overlap = -1; o->h2_persist = -1; o->level_split = -1; o->h2_winograd = -1;
 }
 
 int nst_ctx_create(int device, const float* const* weights, const float* const* biases, nst_ctx** out) {
@@ -870,6 +920,7 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
     hipError_t e = conv_mfma_init_device();
     if (e == hipSuccess) e = conv_bf3_init_device();
     if (e == hipSuccess) e = conv_h2_init_device();
+    if (e == hipSuccess) e = conv_wino_init_device();
     if (e == hipSuccess) e = gram_init_device();
     // options: an explicit argument wins; -1 falls back to the environment (read here, once), then to the default
     if (opts.conv_mode >= 0) {
@@ -891,6 +942,7 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
     ctx->wg256 = (opts.h2_wg256 >= 0 ? opts.h2_wg256 : env_flag("NST_H2_WG256", 0)) ? 1 : 0;
     ctx->tile_rows = opts.h2_tile_rows >= 0 ? opts.h2_tile_rows : env_flag("NST_H2_TILE_ROWS", 0);
     ctx->persist = (opts.h2_persist >= 0 ? opts.h2_persist : env_flag("NST_H2_PERSIST", 0)) ? 1 : 0;
+    ctx->winograd = (opts.h2_winograd >= 0 ? opts.h2_winograd : env_flag("NST_H2_WINOGRAD", 0)) ? 1 : 0;
     ctx->level_split = (opts.level_split >= 0 ? opts.level_split : env_flag("NST_LEVEL_SPLIT", 0)) ? 1 : 0;
     ctx->gram_overlap = (opts.gram_overlap >= 0 ? opts.gram_overlap : env_flag("NST_GRAM_OVERLAP", 0)) ? 1 : 0;
     if (ctx->use_graph && hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "stream creation failed"; return bail(NST_E_HIP); }
@@ -937,6 +989,11 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
             make_h2(tmp.data(), 9, co, ci, tmp16, &ctx->wf_h2_inv[l]);
             if (dev_alloc(ctx, &ctx->wf_h2[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
             if (hipMemcpy(ctx->wf_h2[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+            if (ctx->winograd && ci >= 256 && ci % 64 == 0 && co % 128 == 0 && pool_index_after(l) < 0) {      // (Cin = 128: no gain measured)
+                make_wino(tmp.data(), co, ci, tmp16, &ctx->wf_wino_inv[l]);
+                if (dev_alloc(ctx, &ctx->wf_wino[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
+                if (hipMemcpy(ctx->wf_wino[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+            }
         }
         // input gradient: a conv with "Cout" = ci and "Cin" = co: wd[tap'][ci][co] = W[co][ci][2-ky'][2-kx']
         for (int t = 0; t < 9; ++t) {
@@ -980,7 +1037,7 @@ void nst_ctx_destroy(nst_ctx* ctx) {
     quiesce(ctx);
     for (int i = 0; i < NST_MAX_LEVELS; ++i) free_level(ctx, ctx->lv[i]);
     if (ctx->tail) (void)hipEventDestroy(ctx->tail);
-    for (int l = 0; l < NL; ++l) { dev_free(ctx->wf[l]); dev_free(ctx->wd[l]); dev_free(ctx->bias[l]); dev_free(ctx->wf_bf[l]); dev_free(ctx->wd_bf[l]); dev_free(ctx->wf_h2[l]); dev_free(ctx->wd_h2[l]); }
+    for (int l = 0; l < NL; ++l) { dev_free(ctx->wf[l]); dev_free(ctx->wd[l]); dev_free(ctx->bias[l]); dev_free(ctx->wf_bf[l]); dev_free(ctx->wd_bf[l]); dev_free(ctx->wf_h2[l]); dev_free(ctx->wd_h2[l]); dev_free(ctx->wf_wino[l]); }
     dev_free(ctx->w11k); dev_free(ctx->w11d);
     if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
     if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);

@@ -94,7 +94,14 @@ struct ConvBatch {
     int mfma16, wg256, tile_rows;   // conv_h2: see ConvParams
     int persist;             // conv_h2: in: nst_options.h2_persist; the launcher clears it where the persistent form does not apply
     int total_tiles;         // conv_h2: filled by the launcher (tiles x output-channel tiles)
+    const void* wt_wino;     // conv_wino: the layer's transformed weights in fragment order (nullptr: none)
+    float wt_wino_inv;
 };
+
+// conv_wino.hip: forward 3x3 convolution as 1-D Winograd F(2,3) in the f16x2 arithmetic (nst_options.h2_winograd)
+hipError_t conv_wino_init_device();
+bool conv_wino_eligible(const ConvBatch& b);
+hipError_t launch_conv_wino_batch(const ConvBatch& b, hipStream_t stream);
 
 // conv_mfma.hip
 hipError_t conv_mfma_init_device();

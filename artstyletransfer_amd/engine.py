@@ -40,7 +40,8 @@ class StyleEngine:
                  use_graph: Optional[bool] = None, h2_band_rows: Optional[int] = None, lbfgs_gram: Optional[bool] = None,
                  h2_mfma16: Optional[bool] = None, h2_wg256: Optional[bool] = None,
                  h2_tile_rows: Optional[int] = None, gram_overlap: Optional[bool] = None,
-                 h2_persist: Optional[bool] = None, level_split: Optional[bool] = None):
+                 h2_persist: Optional[bool] = None, level_split: Optional[bool] = None,
+                 h2_winograd: Optional[bool] = None):
         """Options (nst_options): None = environment variable (NST_CONV, NST_BATCH, NST_SINGLE_STREAM, NST_GRAPH,
         NST_H2_BAND_ROWS, NST_LBFGS_GRAM, NST_H2_MFMA16; read once, here) and otherwise the default (f16x2, batched, ...)."""
         self.lib = _lib.load()
@@ -66,7 +67,7 @@ class StyleEngine:
         for name, val in (("batched", batched), ("single_stream", single_stream), ("use_graph", use_graph),
                           ("h2_band_rows", h2_band_rows), ("lbfgs_gram", lbfgs_gram), ("h2_mfma16", h2_mfma16),
                           ("h2_wg256", h2_wg256), ("h2_tile_rows", h2_tile_rows),
-                          ("gram_overlap", gram_overlap), ("h2_persist", h2_persist), ("level_split", level_split)):
+                          ("gram_overlap", gram_overlap), ("h2_persist", h2_persist), ("level_split", level_split), ("h2_winograd", h2_winograd)):
             if val is not None:
                 setattr(opts, name, int(val))
         ctx = C.c_void_p()

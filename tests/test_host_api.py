@@ -49,7 +49,7 @@ def test_options_struct_matches_the_header():
     o = _lib.Options()
     _lib.load().nst_options_default(ctypes.byref(o))
     assert o.struct_size == ctypes.sizeof(_lib.Options)
-    assert [getattr(o, f[0]) for f in _lib.Options._fields_[1:]] == [-1] * 12
+    assert [getattr(o, f[0]) for f in _lib.Options._fields_[1:]] == [-1] * 13
 
 
 def test_no_gpu_is_an_error_not_a_fallback(vgg_weights):
