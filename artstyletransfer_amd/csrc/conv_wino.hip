@@ -1,6 +1,7 @@
-// conv_wino.hip - the 3x3 convolution forward (bias + ReLU + ReLU bit mask) as a 1-D Winograd F(2,3) along x on the fp16
-// matrix pipe, in the f16x2 arithmetic of conv_h2.hip: 1.5x fewer MFMAs per output.  EXPERIMENT behind
-// nst_options.h2_winograd (forward launches with Cin >= 128, Cout a multiple of 128 and no pooling behind them).
+// conv_wino.hip - the 3x3 convolution (forward: bias + ReLU + ReLU bit mask; input gradient: loss-gradient addend + ReLU mask
+// of the map below) as a 1-D Winograd F(2,3) along x on the fp16 matrix pipe, in the f16x2 arithmetic of conv_h2.hip:
+// 1.5x fewer MFMAs per output.  EXPERIMENT behind nst_options.h2_winograd, for the launches with Cin >= 256, Cout a multiple
+// of 128, no pooling on either side of them and no second (Gram) source.
 //
 // For an output pair (x = 2p, 2p + 1) of a row and the input columns d0..d3 = x - 1 .. x + 2 (one tap row ky):
 //     t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3                    (input transform, fp32, before the cut)
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_fwd_batch_kernel(ConvBatch b
                         E[(xi * 64 + mt * 32 + m) * 64 + nt * 32 + l31] = fmaf(accx[mt][nt][r], LO_DOWN, accm[mt][nt][r]) * inv;
                     }
         }
-        if (tid < 256) WB[tid] = 0u;
+        if (im.bits_out && tid < 256) WB[tid] = 0u;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -238,31 +239,49 @@ __global__ __launch_bounds__(512, 2) void conv_wino_fwd_batch_kernel(ConvBatch b
             const int co = n0 + pass * 64 + cq * 4;
             const f32x4 bv = b.bias ? *reinterpret_cast<const f32x4*>(b.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 ya = m0 + m1 + m2 + bv, yb = m1 - m2 - m3 + bv;
+            const int yy = pr >> 3, p = pr & 7;
+            const int gy = y0 + yy, gx = x0 + 2 * p;
+            const bool ina = gy < H && gx < W, inb = gy < H && gx + 1 < W;
+            const size_t pa = (size_t)gy * W + gx;
+            // input-gradient launches: the loss gradient injected at this layer (content), then the ReLU mask of the map
+            // this gradient belongs to (one bit per channel, 32 channels per word)
+            if (im.addend) {
+                if (ina) ya += *reinterpret_cast<const f32x4*>(im.addend + pa * Cout + co);
+                if (inb) yb += *reinterpret_cast<const f32x4*>(im.addend + (pa + 1) * Cout + co);
+            }
+            unsigned ka = 0xFu, kb = 0xFu;
+            if (im.bits_in) {
+                ka = ina ? (im.bits_in[pa * words + (co >> 5)] >> (co & 31)) & 0xFu : 0u;
+                kb = inb ? (im.bits_in[(pa + 1) * words + (co >> 5)] >> (co & 31)) & 0xFu : 0u;
+            }
             unsigned na = 0u, nb = 0u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 if (b.relu) { ya[e] = fmaxf(ya[e], 0.f); yb[e] = fmaxf(yb[e], 0.f); }
+                ya[e] = ((ka >> e) & 1u) ? ya[e] : 0.f;
+                yb[e] = ((kb >> e) & 1u) ? yb[e] : 0.f;
                 na |= (ya[e] > 0.f ? 1u : 0u) << e;
                 nb |= (yb[e] > 0.f ? 1u : 0u) << e;
-                amax = fmaxf(amax, fmaxf(fabsf(ya[e]), fabsf(yb[e])));
+                if (ina) amax = fmaxf(amax, fabsf(ya[e]));
+                if (inb) amax = fmaxf(amax, fabsf(yb[e]));
             }
-            const int yy = pr >> 3, p = pr & 7;
-            const int gy = y0 + yy, gx = x0 + 2 * p;
-            if (gy < H && gx < W) *reinterpret_cast<f32x4*>(im.out + ((size_t)gy * W + gx) * Cout + co) = ya;
-            if (gy < H && gx + 1 < W) *reinterpret_cast<f32x4*>(im.out + ((size_t)gy * W + gx + 1) * Cout + co) = yb;
+            if (ina) *reinterpret_cast<f32x4*>(im.out + pa * Cout + co) = ya;
+            if (inb) *reinterpret_cast<f32x4*>(im.out + (pa + 1) * Cout + co) = yb;
             if (im.bits_out) {
                 const int pix = yy * 16 + 2 * p, w = cq >> 3, sh = (cq & 7) * 4;
                 atomicOr(&WB[pix * 2 + w], na << sh);
                 atomicOr(&WB[(pix + 1) * 2 + w], nb << sh);
             }
         }
-        __syncthreads();
-        if (im.bits_out && tid < 256) {
-            const int pix = tid >> 1, w = tid & 1;
-            const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
-            if (gy < H && gx < W) im.bits_out[((size_t)gy * W + gx) * words + (n0 >> 5) + pass * 2 + w] = WB[tid];
+        __syncthreads();          // (E may be overwritten by the next pass; the mask words are complete)
+        if (im.bits_out) {
+            if (tid < 256) {
+                const int pix = tid >> 1, w = tid & 1;
+                const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
+                if (gy < H && gx < W) im.bits_out[((size_t)gy * W + gx) * words + (n0 >> 5) + pass * 2 + w] = WB[tid];
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (im.amax_out) {
 #pragma unroll
@@ -279,7 +298,7 @@ bool conv_wino_eligible(const ConvBatch& b) {
     if (!b.wt_wino || b.Cin < 128 || b.Cin % 64 != 0 || b.Cout % 128 != 0 || b.unpool || b.Cin2 != 0) return false;
     for (int i = 0; i < b.n; ++i) {
         const ConvImage& im = b.img[i];
-        if (im.in2 || im.addend || im.mask || im.bits_in || im.pool_out || im.pcode_out || !im.amax_in) return false;
+        if (im.in2 || im.mask || im.pool_out || im.pcode_out || !im.amax_in) return false;
         if ((size_t)im.H * im.W * (b.Cin > b.Cout ? b.Cin : b.Cout) * 4 >= 0xFFFFFF00ull) return false;
     }
     return true;

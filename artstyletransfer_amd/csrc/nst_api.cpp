@@ -92,6 +92,8 @@ struct nst_ctx {
     float* wd[NL] = {};
     void* wf_bf[NL] = {};       // the same weights cut into 3 bf16 pieces (conv_bf3.hip layout)
     void* wd_bf[NL] = {};
+    void* wd_wino[NL] = {};     // the same for the input-gradient launches
+    float wd_wino_inv[NL] = {};
     void* wf_wino[NL] = {};     // conv_wino.hip's transformed forward weights (nst_options.h2_winograd), true = pieces * wf_wino_inv
     float wf_wino_inv[NL] = {};
     int winograd = 0;           // nst_options.h2_winograd
@@ -724,6 +726,7 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wd_bf[l]; b.bias = nullptr; b.Cin = kCout[l]; b.Cout = kCin[l]; b.relu = 0;
         b.wt_h2 = ctx->wd_h2[l]; b.wt_h2_inv = ctx->wd_h2_inv[l]; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows; b.persist = ctx->persist;
+        b.wt_wino = ctx->wd_wino[l]; b.wt_wino_inv = ctx->wd_wino_inv[l];
         // f16x2: when a max-pool follows layer l, cur[] holds the gradient w.r.t. the POOLED map and this launch's
         // loader un-pools it through the arg-max code (no un-pool kernel, no full-size gradient round trip)
         const int pl = pool_index_after(l);
@@ -764,7 +767,8 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
         }
         {
             Timer t(ctx, s, K_CONV3, flops, b.img[0].H, b.img[0].W, b.Cin, b.Cout, 9, -l);
-            HIPCHK(ctx, h2 ? launch_conv_h2_batch(b, s) : launch_conv_bf3_batch(b, s));
+            if (h2 && !win && b.wt_wino && conv_wino_eligible(b)) HIPCHK(ctx, launch_conv_wino_batch(b, s));
+            else HIPCHK(ctx, h2 ? launch_conv_h2_batch(b, s) : launch_conv_bf3_batch(b, s));
         }
         for (int k = 0; k < n; ++k) {
             ActSet& a = ctx->lv[lv[k]].acts;
@@ -1011,6 +1015,11 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
             make_h2(tmp.data(), 9, ci, co, tmp16, &ctx->wd_h2_inv[l]);
             if (dev_alloc(ctx, &ctx->wd_h2[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
             if (hipMemcpy(ctx->wd_h2[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+            if (ctx->winograd && co >= 256 && co % 64 == 0 && ci % 128 == 0 && pool_index_after(l) < 0) {
+                make_wino(tmp.data(), ci, co, tmp16, &ctx->wd_wino_inv[l]);
+                if (dev_alloc(ctx, &ctx->wd_wino[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
+                if (hipMemcpy(ctx->wd_wino[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
+            }
         }
     }
     if (ctx->level_split) ctx->gram_overlap = 0;      // (one side stream: the two experiments exclude each other)
@@ -1037,7 +1046,7 @@ void nst_ctx_destroy(nst_ctx* ctx) {
     quiesce(ctx);
     for (int i = 0; i < NST_MAX_LEVELS; ++i) free_level(ctx, ctx->lv[i]);
     if (ctx->tail) (void)hipEventDestroy(ctx->tail);
-    for (int l = 0; l < NL; ++l) { dev_free(ctx->wf[l]); dev_free(ctx->wd[l]); dev_free(ctx->bias[l]); dev_free(ctx->wf_bf[l]); dev_free(ctx->wd_bf[l]); dev_free(ctx->wf_h2[l]); dev_free(ctx->wd_h2[l]); dev_free(ctx->wf_wino[l]); }
+    for (int l = 0; l < NL; ++l) { dev_free(ctx->wf[l]); dev_free(ctx->wd[l]); dev_free(ctx->bias[l]); dev_free(ctx->wf_bf[l]); dev_free(ctx->wd_bf[l]); dev_free(ctx->wf_h2[l]); dev_free(ctx->wd_h2[l]); dev_free(ctx->wf_wino[l]); dev_free(ctx->wd_wino[l]); }
     dev_free(ctx->w11k); dev_free(ctx->w11d);
     if (ctx->gexec) (void)hipGraphExecDestroy(ctx->gexec);
     if (ctx->gstream) (void)hipStreamDestroy(ctx->gstream);
