@@ -17,6 +17,7 @@ no data-path collective, `value` is the whole-node closure rate, scaling is weak
 Beside the headline (N = 1 only, after the timed region; none of it is inside `value`):
   exact_f32        the same job on the exact fp32 MFMA (nst_options.conv_mode = f32), priced against the 157.3 TF fp32 peak;
   sustained        the headline job kept running for >= 5 s whatever --steps says, with the shader clock sampled from sysfs;
+  winograd_experiment  the same job with nst_options.h2_winograd (conv_wino.hip), a parity-tested experiment that is not the default
   progressing_job  jobs whose image moves at every step (Adam; L-BFGS with the 25-evaluation line search), so that the
                    optimiser update with a filling curvature history is in a driver-seen number;
   cpu_baseline     the oracle timed on this box's host cores on a bounded sample of the same job.
@@ -549,6 +550,13 @@ def main():
             ol.close()
             el.close()
             out["progressing_job"] = prog
+            # ---- the experimental Winograd F(2,3) path on the same job (nst_options.h2_winograd; not in `value`)
+            wg, ew, ow, _ = side_job(args, args.optimizer, args.lbfgs_max_eval, 20 * per_step, 2 * per_step, h2_winograd=True)
+            ow.close()
+            ew.close()
+            wg["what"] = ("the same job with the plain Cin >= 256 conv launches (10 of 24) as a 1-D Winograd F(2,3) in the same "
+                          "f16x2 arithmetic (conv_wino.hip): 1.5x fewer MFMAs there; parity-tested, not the default")
+            out["winograd_experiment"] = wg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(job_host, cfg, args.cpu_closures)
         print(json.dumps(out), flush=True)
