@@ -40,9 +40,10 @@ constexpr int W_PROWB = 4 * W_PAIRS * W_ROWB + 128;      // a patch row: [xi][pa
                                                          // (16 lanes = 2 rows x 8 pairs) land on complementary 16-byte slots
 constexpr int W_A_BYTES = W_PH * W_PROWB;
 constexpr int W_E_BYTES = 4 * 64 * 64 * 4;               // epilogue: m[xi][pair row][64 channels] fp32
-constexpr int W_BITS_OFF = W_E_BYTES;                    // + 128 pixels x 2 words
+constexpr int W_BITS_OFF = W_E_BYTES;                    // + 128 pixels x 2 ReLU-mask words
+constexpr int W_CODE_OFF = W_BITS_OFF + 128 * 2 * 4;     // + 32 pooled pixels x 2 words x 4 window positions
 constexpr int W_LDS = 2 * W_A_BYTES;
-static_assert(W_E_BYTES + 128 * 2 * 4 <= W_LDS, "the epilogue reuses the patch buffers");
+static_assert(W_CODE_OFF + 32 * 2 * 4 * 4 <= W_LDS, "the epilogue reuses the patch buffers");
 constexpr float LO_UP = 2048.f, LO_DOWN = 1.f / 2048.f;
 
 __device__ __forceinline__ void cut2x4(const f32x4 v, const float s, u32x2& hi, u32x2& lo) {
@@ -63,7 +64,10 @@ __device__ __forceinline__ int xcd_order(const int b, const int grid) {
 
 }  // namespace
 
-__global__ __launch_bounds__(512, 2) void conv_wino_fwd_batch_kernel(ConvBatch b) {
+// UNPOOL: every image's `in` is the gradient w.r.t. a 2x2-pooled map; the loader un-pools it through the arg-max code words
+// (conv_h2.hip's rule: [pooled pixel][32-channel group][window position], bit = channel & 31).
+template <bool UNPOOL>
+__global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int xi = wave & 3, wn = wave >> 2;
@@ -98,7 +102,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_fwd_batch_kernel(ConvBatch b
     }
     const float inv = ia * b.wt_wino_inv;
 
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(im.in), 0, (unsigned)((size_t)H * W * Cin * 4), 0x00020000);
+    const int PH2 = H >> 1, PW2 = W >> 1;
+    const size_t in_px = UNPOOL ? (size_t)PH2 * PW2 : (size_t)H * W;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(im.in), 0, (unsigned)(in_px * Cin * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_code = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned*>(UNPOOL ? im.pcode_in : nullptr), 0, UNPOOL ? (unsigned)(in_px * (Cin >> 5) * 16) : 0u, 0x00020000);
     const f16x8* __restrict__ wimg = reinterpret_cast<const f16x8*>(b.wt_wino);
 
     f32x16 accm[2][2], accx[2][2];
@@ -110,20 +118,39 @@ __global__ __launch_bounds__(512, 2) void conv_wino_fwd_batch_kernel(ConvBatch b
             for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accx[a][c][r] = 0.f; }
 
     // ---- patch staging: task u = (patch row, pair, channel quad): four pixels in, four transformed units out
-    auto task_voff = [&](int u, int j) -> unsigned {
+    struct Stage { f32x4 d[4]; unsigned code[UNPOOL ? 4 : 1]; };
+    auto task_load = [&](Stage& st, int u, int chunk) {
         const int row = u >> 6, pair = (u >> 3) & 7, quad = u & 7;
-        const int gy = y0 - 1 + row, gx = x0 + 2 * pair - 1 + j;
-        const bool ok = (u < W_PH * 64) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-        return ok ? ((unsigned)(gy * W + gx) * (unsigned)Cin + (unsigned)quad * 4u) * 4u : 0xFFFFFF00u;
-    };
-    auto task_load = [&](f32x4 (&d)[4], int u, int chunk) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, task_voff(u, j), chunk * 128, 0));
+        for (int j = 0; j < 4; ++j) {
+            const int gy = y0 - 1 + row, gx = x0 + 2 * pair - 1 + j;
+            bool ok = (u < W_PH * 64) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+            if (!UNPOOL) {
+                const unsigned voff = ok ? ((unsigned)(gy * W + gx) * (unsigned)Cin + (unsigned)quad * 4u) * 4u : 0xFFFFFF00u;
+                st.d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, chunk * 128, 0));
+            } else {
+                ok = ok & ((gy >> 1) < PH2) & ((gx >> 1) < PW2);          // the odd last row / column belongs to no window
+                const unsigned pp = (unsigned)((gy >> 1) * PW2 + (gx >> 1));
+                const unsigned voff = ok ? (pp * (unsigned)Cin + (unsigned)quad * 4u) * 4u : 0xFFFFFF00u;
+                const unsigned coff = ok ? ((pp * (unsigned)(Cin >> 5)) * 4u + (unsigned)((gy & 1) * 2 + (gx & 1))) * 4u : 0xFFFFFF00u;
+                st.d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, chunk * 128, 0));
+                st.code[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_code, coff, chunk * 16, 0);
+            }
+        }
     };
-    auto task_store = [&](const f32x4 (&d)[4], int u, unsigned char* buf) {
+    auto task_store = [&](const Stage& st, int u, unsigned char* buf) {
         if (u >= W_PH * 64) return;
         const int row = u >> 6, pair = (u >> 3) & 7, quad = u & 7;
+        f32x4 d[4] = {st.d[0], st.d[1], st.d[2], st.d[3]};
+        if (UNPOOL) {
+            // an element of the pooled gradient goes to the window position that held the (first, positive) maximum
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const unsigned bits = st.code[UNPOOL ? j : 0] >> (quad * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) d[j][k] = ((bits >> k) & 1u) ? d[j][k] : 0.f;
+            }
+        }
         const f32x4 tt[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
         unsigned char* base = buf + row * W_PROWB + pair * W_ROWB + quad * 8;
 #pragma unroll
@@ -167,7 +194,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_fwd_batch_kernel(ConvBatch b
     };
 
     // ---- prologue: chunk 0 into buffer 0, the first two k-steps' weights on their way
-    f32x4 d[4], d2[4];      // staging of the two patch tasks of a thread (the second exists for waves 0 and 1 only)
+    Stage d, d2;            // staging of the two patch tasks of a thread (the second exists for waves 0 and 1 only)
     BF B[3];
     AF A[2];
     {
@@ -209,11 +236,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino_fwd_batch_kernel(ConvBatch b
         if (c + 1 < nch) read_a(A[0], nxt, 0, 0);
     }
 
-    // ---- epilogue: the four xi accumulators of every pair meet in LDS, one output-channel half at a time
+    // ---- epilogue: the four xi accumulators of every pair meet in LDS, one output-channel half at a time.  A thread then
+    // owns a 2x2 pixel window (image rows 2 yp, 2 yp + 1 of the tile, output pair p) x 4 channels: output transform, bias /
+    // addend, ReLU / ReLU mask, 16-byte stores, and - where a pooling layer follows - the window's maximum and arg-max code.
     float* E = reinterpret_cast<float*>(smem);                               // [xi][pair row 64][64]
     unsigned* WB = reinterpret_cast<unsigned*>(smem + W_BITS_OFF);           // [pixel 128][2 words]
+    unsigned* PC = reinterpret_cast<unsigned*>(smem + W_CODE_OFF);           // [pooled pixel 32][2 words][4 positions]
     const int words = Cout >> 5;
     float amax = 0.f;
+    const int yp = tid >> 7, p = (tid >> 4) & 7, cq = tid & 15;
     for (int pass = 0; pass < 2; ++pass) {
         if (wn == pass) {
 #pragma unroll
@@ -227,19 +258,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino_fwd_batch_kernel(ConvBatch b
                     }
         }
         if (im.bits_out && tid < 256) WB[tid] = 0u;
+        if (im.pcode_out && tid >= 256) PC[tid - 256] = 0u;
         __syncthreads();
+        const int co = n0 + pass * 64 + cq * 4;
+        const f32x4 bv = b.bias ? *reinterpret_cast<const f32x4*>(b.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const int w = cq >> 3, sh = (cq & 7) * 4;
+        f32x4 win[2][2];                  // [row of the window][column]
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            const int task = tid + k * 512;            // (pair row, channel quad)
-            const int pr = task >> 4, cq = task & 15;
+            const int yy = 2 * yp + k, pr = yy * 8 + p;
             const f32x4 m0 = *reinterpret_cast<const f32x4*>(E + (0 * 64 + pr) * 64 + cq * 4);
             const f32x4 m1 = *reinterpret_cast<const f32x4*>(E + (1 * 64 + pr) * 64 + cq * 4);
             const f32x4 m2 = *reinterpret_cast<const f32x4*>(E + (2 * 64 + pr) * 64 + cq * 4);
             const f32x4 m3 = *reinterpret_cast<const f32x4*>(E + (3 * 64 + pr) * 64 + cq * 4);
-            const int co = n0 + pass * 64 + cq * 4;
-            const f32x4 bv = b.bias ? *reinterpret_cast<const f32x4*>(b.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
             f32x4 ya = m0 + m1 + m2 + bv, yb = m1 - m2 - m3 + bv;
-            const int yy = pr >> 3, p = pr & 7;
             const int gy = y0 + yy, gx = x0 + 2 * p;
             const bool ina = gy < H && gx < W, inb = gy < H && gx + 1 < W;
             const size_t pa = (size_t)gy * W + gx;
@@ -268,17 +300,49 @@ __global__ __launch_bounds__(512, 2) void conv_wino_fwd_batch_kernel(ConvBatch b
             if (ina) *reinterpret_cast<f32x4*>(im.out + pa * Cout + co) = ya;
             if (inb) *reinterpret_cast<f32x4*>(im.out + (pa + 1) * Cout + co) = yb;
             if (im.bits_out) {
-                const int pix = yy * 16 + 2 * p, w = cq >> 3, sh = (cq & 7) * 4;
+                const int pix = yy * 16 + 2 * p;
                 atomicOr(&WB[pix * 2 + w], na << sh);
                 atomicOr(&WB[(pix + 1) * 2 + w], nb << sh);
             }
+            win[k][0] = ya; win[k][1] = yb;
         }
-        __syncthreads();          // (E may be overwritten by the next pass; the mask words are complete)
-        if (im.bits_out) {
-            if (tid < 256) {
-                const int pix = tid >> 1, w = tid & 1;
+        const int py = (y0 + 2 * yp) >> 1, px = (x0 + 2 * p) >> 1;
+        const bool inw = py < PH2 && px < PW2;
+        if (im.pool_out) {
+            // 2x2/2 max pool (+ the arg-max code the un-pooling loader of the backward pass reads: the window's FIRST maximum,
+            // where it is positive - max_pool2d's backward and the ReLU mask of the pooled activation in one)
+            f32x4 mx;
+            unsigned cn[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float e0 = win[0][0][e], e1 = win[0][1][e], e2 = win[1][0][e], e3 = win[1][1][e];
+                mx[e] = fmaxf(fmaxf(e0, e1), fmaxf(e2, e3));
+                int pos = 0;
+                float best = e0;
+                if (e1 > best) { best = e1; pos = 1; }
+                if (e2 > best) { best = e2; pos = 2; }
+                if (e3 > best) { best = e3; pos = 3; }
+                const bool live = best > 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cn[q] |= ((live && pos == q) ? 1u : 0u) << e;
+            }
+            if (inw) *reinterpret_cast<f32x4*>(im.pool_out + ((size_t)py * PW2 + px) * Cout + co) = mx;
+            if (im.pcode_out) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) atomicOr(&PC[((yp * 8 + p) * 2 + w) * 4 + q], cn[q] << sh);
+            }
+        }
+        __syncthreads();          // (E may be overwritten by the next pass; the mask and code words are complete)
+        if (im.bits_out || im.pcode_out) {
+            if (im.bits_out && tid < 256) {
+                const int pix = tid >> 1, w2 = tid & 1;
                 const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
-                if (gy < H && gx < W) im.bits_out[((size_t)gy * W + gx) * words + (n0 >> 5) + pass * 2 + w] = WB[tid];
+                if (gy < H && gx < W) im.bits_out[((size_t)gy * W + gx) * words + (n0 >> 5) + pass * 2 + w2] = WB[tid];
+            }
+            if (im.pcode_out && tid >= 256) {
+                const int i = tid - 256, pp = i >> 3, w2 = (i >> 2) & 1, q = i & 3;
+                const int qy = (y0 >> 1) + (pp >> 3), qx = (x0 >> 1) + (pp & 7);
+                if (qy < PH2 && qx < PW2) im.pcode_out[(((size_t)qy * PW2 + qx) * words + (n0 >> 5) + pass * 2 + w2) * 4 + q] = PC[i];
             }
             __syncthreads();
         }
@@ -291,14 +355,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino_fwd_batch_kernel(ConvBatch b
 }
 
 hipError_t conv_wino_init_device() {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_fwd_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_batch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_batch_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
 }
 
 bool conv_wino_eligible(const ConvBatch& b) {
-    if (!b.wt_wino || b.Cin < 128 || b.Cin % 64 != 0 || b.Cout % 128 != 0 || b.unpool || b.Cin2 != 0) return false;
+    if (!b.wt_wino || b.Cin < 128 || b.Cin % 64 != 0 || b.Cout % 128 != 0 || b.Cin2 != 0) return false;
+    // the un-pooling loader (three pooled pixels + their code words per task, 28 spilled registers) is SLOWER than the direct
+    // kernel's: 0.39 -> 0.49 ms on conv3_4's input gradient; parity-green, taken only at h2_winograd = 2
+    if (b.unpool && b.wino_level < 2) return false;
     for (int i = 0; i < b.n; ++i) {
         const ConvImage& im = b.img[i];
-        if (im.in2 || im.mask || im.pool_out || im.pcode_out || !im.amax_in) return false;
+        if (im.in2 || im.mask || !im.amax_in || (b.unpool != 0) != (im.pcode_in != nullptr)) return false;
+        if (im.pcode_out && !im.pool_out) return false;
         if ((size_t)im.H * im.W * (b.Cin > b.Cout ? b.Cin : b.Cout) * 4 >= 0xFFFFFF00ull) return false;
     }
     return true;
@@ -313,7 +383,8 @@ hipError_t launch_conv_wino_batch(const ConvBatch& b0, hipStream_t stream) {
         tiles += b.img[i].tiles_x * ((b.img[i].H + W_TH - 1) / W_TH);
         b.img[i].tile_end = tiles;
     }
-    hipLaunchKernelGGL(conv_wino_fwd_batch_kernel, dim3(tiles * (b.Cout / 128)), dim3(512), W_LDS, stream, b);
+    if (b.unpool) hipLaunchKernelGGL(conv_wino_batch_kernel<true>, dim3(tiles * (b.Cout / 128)), dim3(512), W_LDS, stream, b);
+    else hipLaunchKernelGGL(conv_wino_batch_kernel<false>, dim3(tiles * (b.Cout / 128)), dim3(512), W_LDS, stream, b);
     return hipGetLastError();
 }
 

@@ -607,7 +607,7 @@ int batched_forward(nst_ctx* ctx, const float* const* xi, const int* lv, int n, 
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wf_bf[l]; b.bias = ctx->bias[l]; b.Cin = kCin[l]; b.Cout = kCout[l]; b.relu = 1;
         b.wt_h2 = ctx->wf_h2[l]; b.wt_h2_inv = ctx->wf_h2_inv[l]; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows; b.persist = ctx->persist;
-        b.wt_wino = ctx->wf_wino[l]; b.wt_wino_inv = ctx->wf_wino_inv[l];
+        b.wt_wino = ctx->wf_wino[l]; b.wt_wino_inv = ctx->wf_wino_inv[l]; b.wino_level = ctx->winograd;
         double flops = 0;
         for (int k = 0; k < n; ++k) {
             ActSet& a = ctx->lv[lv[k]].acts;
@@ -726,7 +726,7 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wd_bf[l]; b.bias = nullptr; b.Cin = kCout[l]; b.Cout = kCin[l]; b.relu = 0;
         b.wt_h2 = ctx->wd_h2[l]; b.wt_h2_inv = ctx->wd_h2_inv[l]; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows; b.persist = ctx->persist;
-        b.wt_wino = ctx->wd_wino[l]; b.wt_wino_inv = ctx->wd_wino_inv[l];
+        b.wt_wino = ctx->wd_wino[l]; b.wt_wino_inv = ctx->wd_wino_inv[l]; b.wino_level = ctx->winograd;
         // f16x2: when a max-pool follows layer l, cur[] holds the gradient w.r.t. the POOLED map and this launch's
         // loader un-pools it through the arg-max code (no un-pool kernel, no full-size gradient round trip)
         const int pl = pool_index_after(l);
@@ -946,7 +946,7 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
     ctx->wg256 = (opts.h2_wg256 >= 0 ? opts.h2_wg256 : env_flag("NST_H2_WG256", 0)) ? 1 : 0;
     ctx->tile_rows = opts.h2_tile_rows >= 0 ? opts.h2_tile_rows : env_flag("NST_H2_TILE_ROWS", 0);
     ctx->persist = (opts.h2_persist >= 0 ? opts.h2_persist : env_flag("NST_H2_PERSIST", 0)) ? 1 : 0;
-    ctx->winograd = (opts.h2_winograd >= 0 ? opts.h2_winograd : env_flag("NST_H2_WINOGRAD", 0)) ? 1 : 0;
+    ctx->winograd = opts.h2_winograd >= 0 ? opts.h2_winograd : env_flag("NST_H2_WINOGRAD", 0);
     ctx->level_split = (opts.level_split >= 0 ? opts.level_split : env_flag("NST_LEVEL_SPLIT", 0)) ? 1 : 0;
     ctx->gram_overlap = (opts.gram_overlap >= 0 ? opts.gram_overlap : env_flag("NST_GRAM_OVERLAP", 0)) ? 1 : 0;
     if (ctx->use_graph && hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "stream creation failed"; return bail(NST_E_HIP); }
@@ -993,7 +993,7 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
             make_h2(tmp.data(), 9, co, ci, tmp16, &ctx->wf_h2_inv[l]);
             if (dev_alloc(ctx, &ctx->wf_h2[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
             if (hipMemcpy(ctx->wf_h2[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
-            if (ctx->winograd && ci >= 256 && ci % 64 == 0 && co % 128 == 0 && pool_index_after(l) < 0) {      // (Cin = 128: no gain measured)
+            if (ctx->winograd && ci >= 256 && ci % 64 == 0 && co % 128 == 0) {      // (Cin = 128: no gain measured)
                 make_wino(tmp.data(), co, ci, tmp16, &ctx->wf_wino_inv[l]);
                 if (dev_alloc(ctx, &ctx->wf_wino[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
                 if (hipMemcpy(ctx->wf_wino[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
@@ -1015,7 +1015,7 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
             make_h2(tmp.data(), 9, ci, co, tmp16, &ctx->wd_h2_inv[l]);
             if (dev_alloc(ctx, &ctx->wd_h2[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
             if (hipMemcpy(ctx->wd_h2[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
-            if (ctx->winograd && co >= 256 && co % 64 == 0 && ci % 128 == 0 && pool_index_after(l) < 0) {
+            if (ctx->winograd && co >= 256 && co % 64 == 0 && ci % 128 == 0) {
                 make_wino(tmp.data(), ci, co, tmp16, &ctx->wd_wino_inv[l]);
                 if (dev_alloc(ctx, &ctx->wd_wino[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
                 if (hipMemcpy(ctx->wd_wino[l], tmp16.data(), tmp16.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }

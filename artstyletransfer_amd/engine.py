@@ -41,7 +41,7 @@ class StyleEngine:
                  h2_mfma16: Optional[bool] = None, h2_wg256: Optional[bool] = None,
                  h2_tile_rows: Optional[int] = None, gram_overlap: Optional[bool] = None,
                  h2_persist: Optional[bool] = None, level_split: Optional[bool] = None,
-                 h2_winograd: Optional[bool] = None):
+                 h2_winograd: Optional[int] = None):
         """Options (nst_options): None = environment variable (NST_CONV, NST_BATCH, NST_SINGLE_STREAM, NST_GRAPH,
         NST_H2_BAND_ROWS, NST_LBFGS_GRAM, NST_H2_MFMA16; read once, here) and otherwise the default (f16x2, batched, ...)."""
         self.lib = _lib.load()

@@ -98,7 +98,8 @@ typedef struct nst_options {
     int h2_winograd;      /* f16x2 batched closure, EXPERIMENT: 1 = the forward launches with Cin >= 128, Cout a multiple of 128 and
                              no pooling behind them (conv3_2, conv3_3, conv4_1 ... conv4_3, conv5_1) run as a 1-D Winograd F(2,3)
                              along x (conv_wino.hip: 1.5x fewer MFMAs, a few 1e-7 of extra rounding in those feature maps);
-                             0 = direct convolution everywhere; -1: env NST_H2_WINOGRAD, default 0 */
+                             2 = also the input-gradient launches that un-pool (slower there); 0 = direct convolution everywhere;
+                             -1: env NST_H2_WINOGRAD, default 0 */
 } nst_options;
 void nst_options_default(nst_options* opts);
 int nst_ctx_create_ex(int device, const float* const* weights, const float* const* biases, const nst_options* opts,

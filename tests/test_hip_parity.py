@@ -353,8 +353,9 @@ def test_experiment_switches_agree_with_the_default(vgg_weights, opts):
         np.testing.assert_allclose(l1, l0, rtol=1e-5)
 
 
+@pytest.mark.parametrize("level", [1, 2])
 @pytest.mark.parametrize("h,w,nlev", [(128, 192, 2), (200, 280, 3), (72, 100, 2)])
-def test_winograd_forward_vs_oracle(vgg_weights, h, w, nlev):
+def test_winograd_forward_vs_oracle(vgg_weights, h, w, nlev, level):
     """nst_options.h2_winograd (conv_wino.hip: the forward convolutions with Cin >= 256 and no pooling behind them as a 1-D
     Winograd F(2,3) in the f16x2 arithmetic) against the ORACLE like every other schedule: losses 1e-5, the whole gradient
     2e-5 under the device pass's own ReLU / pooling / TV-sign decisions, per loss term; edge tiles (280 = 17.5 x 16 columns,
@@ -364,10 +365,10 @@ def test_winograd_forward_vs_oracle(vgg_weights, h, w, nlev):
     c, s = _levels(h, w, nlev, 41), _levels(h - 16, w + 8, nlev, 42)
     xt = cpu_ref.prepare_img((0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(h, w, seed=43)).astype(np.float32))
     tg = oracle_targets(c, s, vgg_weights)
-    e = StyleEngine(vgg_weights, 0, h2_winograd=True)
+    e = StyleEngine(vgg_weights, 0, h2_winograd=level)      # (2: also the un-pooling input-gradient launches)
     try:
         _setup(e, c, s)
-        closure_vs_oracle_under_equal_decisions(e, xt, tg, vgg_weights, f"winograd forward {h}x{w} L{nlev - 1}")
+        closure_vs_oracle_under_equal_decisions(e, xt, tg, vgg_weights, f"winograd level {level} {h}x{w} L{nlev - 1}")
         e.closure(dev(xt), CW, SW, TVW)
         acts = e.level_activations(0)
         w64 = [(a.double(), b.double()) for a, b in vgg_weights]
