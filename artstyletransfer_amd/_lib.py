@@ -100,6 +100,7 @@ SYMBOLS = {
     "nst_dump_last_closure": (C.c_int, [c_void]),
     "nst_timing_totals": (C.c_int, [c_void, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_long),
                                     C.POINTER(C.c_double), C.c_int]),
+    "nst_timing_mfma_flops": (C.c_int, [c_void, C.c_int, C.POINTER(C.c_double)]),
 }
 
 _lib = None

@@ -69,7 +69,7 @@ __device__ __forceinline__ int xcd_order(const int b, const int grid) {
 template <bool UNPOOL>
 __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xi = wave & 3, wn = wave >> 2;
     const int half = lane >> 5, l31 = lane & 31;
 
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     const int sp_all = t / n_ct, ct = t - sp_all * n_ct;
     int ii = 0;
     while (ii + 1 < b.n && sp_all >= b.img[ii].tile_end) ++ii;
+    ii = __builtin_amdgcn_readfirstlane(ii);      // (provably wave-uniform: the image's pointers then live in scalar registers)
     const ConvImage& im = b.img[ii];
     const int sp = sp_all - (ii ? b.img[ii - 1].tile_end : 0);
     const int H = im.H, W = im.W, Cin = b.Cin, Cout = b.Cout;
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
             m = o > m ? o : m;
         }
         int e = (int)((m >> 23) & 0xFFu);
-        e = e < 32 ? 32 : (e > 250 ? 250 : e);
+        e = __builtin_amdgcn_readfirstlane(e < 32 ? 32 : (e > 250 ? 250 : e));      // (the same in every lane: scalar registers)
         sa = __uint_as_float((unsigned)(267 - e) << 23);      // 2^(13 - (e - 127))
         ia = __uint_as_float((unsigned)(e - 13) << 23);
     }
@@ -107,7 +108,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(im.in), 0, (unsigned)(in_px * Cin * 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_code = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<unsigned*>(UNPOOL ? im.pcode_in : nullptr), 0, UNPOOL ? (unsigned)(in_px * (Cin >> 5) * 16) : 0u, 0x00020000);
-    const f16x8* __restrict__ wimg = reinterpret_cast<const f16x8*>(b.wt_wino);
+    // (the weight image through a buffer descriptor: per-lane offset lane * 16, everything else scalar or immediate)
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<void*>(b.wt_wino), 0, (unsigned)((size_t)(Cout >> 7) * nch * 3 * 8 * 2 * 4 * 64 * 16), 0x00020000);
 
     f32x16 accm[2][2], accx[2][2];
 #pragma unroll
@@ -162,6 +165,48 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
         }
     };
 
+    // The last two patch rows (8 pairs x 32 channels each = 512 one-channel tasks) are every thread's second task: four
+    // 4-byte loads, one channel through the same transform and cut.  (As 128 more four-channel tasks they kept 16 staging
+    // registers of EVERY thread busy for two waves' sake.)
+    struct Stage1 { float d[4]; unsigned code[UNPOOL ? 4 : 1]; };
+    auto row_load = [&](Stage1& st, int u, int chunk) {
+        const int row = 8 + (u >> 8), pair = (u >> 5) & 7, ch = u & 31;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gy = y0 - 1 + row, gx = x0 + 2 * pair - 1 + j;
+            bool ok = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
+            if (!UNPOOL) {
+                const unsigned voff = ok ? ((unsigned)(gy * W + gx) * (unsigned)Cin + (unsigned)ch) * 4u : 0xFFFFFF00u;
+                st.d[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, chunk * 128, 0));
+            } else {
+                ok = ok & ((gy >> 1) < PH2) & ((gx >> 1) < PW2);
+                const unsigned pp = (unsigned)((gy >> 1) * PW2 + (gx >> 1));
+                const unsigned voff = ok ? (pp * (unsigned)Cin + (unsigned)ch) * 4u : 0xFFFFFF00u;
+                const unsigned coff = ok ? ((pp * (unsigned)(Cin >> 5)) * 4u + (unsigned)((gy & 1) * 2 + (gx & 1))) * 4u : 0xFFFFFF00u;
+                st.d[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, chunk * 128, 0));
+                st.code[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_code, coff, chunk * 16, 0);
+            }
+        }
+    };
+    auto row_store = [&](const Stage1& st, int u, unsigned char* buf) {
+        const int row = 8 + (u >> 8), pair = (u >> 5) & 7, ch = u & 31;
+        float d[4] = {st.d[0], st.d[1], st.d[2], st.d[3]};
+        if (UNPOOL) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) d[j] = ((st.code[UNPOOL ? j : 0] >> ch) & 1u) ? d[j] : 0.f;
+        }
+        const float tt[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
+        unsigned char* base = buf + row * W_PROWB + pair * W_ROWB + ch * 2;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const float v = tt[x] * sa;
+            const _Float16 hi = (_Float16)v;
+            const _Float16 lo = (_Float16)((v - (float)hi) * LO_UP);
+            *reinterpret_cast<_Float16*>(base + x * W_PAIRS * W_ROWB) = hi;
+            *reinterpret_cast<_Float16*>(base + x * W_PAIRS * W_ROWB + 64) = lo;
+        }
+    };
+
     // ---- fragments
     // A: lane (r = l31, h = half) holds A[pair row r of the m tile][k = 8 h + j]; pair row = 4 image rows x 8 pairs
     const int a_base = ((l31 >> 3)) * W_PROWB + (xi * W_PAIRS + (l31 & 7)) * W_ROWB + half * 16;
@@ -176,11 +221,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     // B: 16-byte units [ct][chunk][ky][wave][ks][nt][piece][lane]
     struct BF { f16x8 v[2][2]; };       // [n tile][piece]
     auto load_b = [&](BF& f, int chunk, int ky, int ks) {
-        const size_t u0 = ((((size_t)(ct * nch + chunk) * 3 + ky) * 8 + wave) * 2 + ks) * 4 * 64 + lane;
+        const int soff = (((((ct * nch + chunk) * 3 + ky) * 8 + wave) * 2 + ks) * 4 * 64) * 16;
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) f.v[nt][s] = wimg[u0 + (size_t)(nt * 2 + s) * 64];
+            for (int s = 0; s < 2; ++s)
+                f.v[nt][s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16 + (nt * 2 + s) * 64 * 16, soff, 0));
     };
     auto multiply = [&](const AF& a, const BF& w) {
 #pragma unroll
@@ -194,7 +240,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     };
 
     // ---- prologue: chunk 0 into buffer 0, the first two k-steps' weights on their way
-    Stage d, d2;            // staging of the two patch tasks of a thread (the second exists for waves 0 and 1 only)
+    Stage d;                // staging of a thread's four-channel task (patch rows 0 - 7) ...
+    Stage1 d1;              // ... and of its one-channel task (patch rows 8, 9)
     BF B[3];
     AF A[2];
     {
@@ -202,10 +249,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
         load_b(B[0], 0, 0, 0);
         load_b(B[1], 0, 0, 1);
         task_store(d, tid, smem);
-        if (tid < W_PH * 64 - 512) {
-            task_load(d, tid + 512, 0);
-            task_store(d, tid + 512, smem);
-        }
+        row_load(d1, tid, 0);
+        row_store(d1, tid, smem);
     }
     __syncthreads();
     read_a(A[0], smem, 0, 0);
@@ -216,6 +261,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
         const unsigned char* cur = smem + (c & 1) * W_A_BYTES;
         unsigned char* nxt = smem + ((c + 1) & 1) * W_A_BYTES;
         const int cn = (c + 1 < nch) ? c + 1 : c;          // (last chunk: a dummy re-load, nobody reads the result)
+        // (the staging addresses are recomputed per chunk from a thread id the compiler cannot see through: hoisted out of
+        // the loop they would sit in eight registers the accumulators and fragments need)
+        int to = tid;
+        asm volatile("" : "+v"(to));
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             // weights two k-steps ahead
@@ -224,13 +273,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
                 if (q2 < 6) load_b(B[q2 % 3], c, q2 >> 1, q2 & 1);
                 else load_b(B[q2 % 3], cn, (q2 - 6) >> 1, (q2 - 6) & 1);
             }
-            if (q == 0) task_load(d, tid, cn);
-            if (q == 1 && tid < W_PH * 64 - 512) task_load(d2, tid + 512, cn);
+            if (q == 0) task_load(d, to, cn);
+            if (q == 1) row_load(d1, to, cn);
             // next k-step's A fragments
             if (q + 1 < 6) read_a(A[(q + 1) & 1], cur, (q + 1) >> 1, (q + 1) & 1);
             multiply(A[q & 1], B[q % 3]);
-            if (q == 4) task_store(d, tid, nxt);
-            if (q == 5 && tid < W_PH * 64 - 512) task_store(d2, tid + 512, nxt);
+            if (q == 4) task_store(d, to, nxt);
+            if (q == 5) row_store(d1, to, nxt);
         }
         __syncthreads();
         if (c + 1 < nch) read_a(A[0], nxt, 0, 0);
@@ -362,9 +411,6 @@ hipError_t conv_wino_init_device() {
 
 bool conv_wino_eligible(const ConvBatch& b) {
     if (!b.wt_wino || b.Cin < 128 || b.Cin % 64 != 0 || b.Cout % 128 != 0 || b.Cin2 != 0) return false;
-    // the un-pooling loader (three pooled pixels + their code words per task, 28 spilled registers) is SLOWER than the direct
-    // kernel's: 0.39 -> 0.49 ms on conv3_4's input gradient; parity-green, taken only at h2_winograd = 2
-    if (b.unpool && b.wino_level < 2) return false;
     for (int i = 0; i < b.n; ++i) {
         const ConvImage& im = b.img[i];
         if (im.in2 || im.mask || !im.amax_in || (b.unpool != 0) != (im.pcode_in != nullptr)) return false;

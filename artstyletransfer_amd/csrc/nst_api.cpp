@@ -58,7 +58,7 @@ inline unsigned* amax_grad(const ActSet& a, int l) { return a.amax + (size_t)(NS
 
 enum KClass { K_CONV3 = 0, K_GRAM = 1, K_CONV1 = 2, K_OTHER = 3, K_NCLASS = 4 };
 
-struct TimedLaunch { hipEvent_t a, b; int cls; double flops; int tag[6]; };
+struct TimedLaunch { hipEvent_t a, b; int cls; double flops; int tag[6]; double mfma_factor; };      // mfma_factor: executed matrix-pipe FLOPs per algorithmic FLOP (< 0: the arithmetic mode's)
 
 struct LevelWs {
     int h = 0, w = 0;
@@ -140,6 +140,7 @@ struct nst_ctx {
     // accumulated over closures since the last reset (timing mode 2)
     double acc_ms[4] = {0, 0, 0, 0};
     double acc_flops[4] = {0, 0, 0, 0};
+    double acc_mfma[4] = {0, 0, 0, 0};          // executed matrix-pipe FLOPs of the timed launches
     long acc_launches[4] = {0, 0, 0, 0};
     double acc_closure_ms = 0;
     long acc_closures = 0;
@@ -349,7 +350,7 @@ struct Timer {
         : ctx(c), s(st), on(false), slot(0) {
         if (c->timing >= 2 && (c->timing < 3 || cls == K_CONV3) && c->sample_now && c->ev_used + 2 <= c->ev_pool.size()) {
             on = true;
-            TimedLaunch t{c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1], cls, flops, {t0, t1, t2, t3, t4, t5}};
+            TimedLaunch t{c->ev_pool[c->ev_used], c->ev_pool[c->ev_used + 1], cls, flops, {t0, t1, t2, t3, t4, t5}, -1.0};
             c->ev_used += 2;
             slot = c->timed.size();
             c->timed.push_back(t);
@@ -357,6 +358,8 @@ struct Timer {
         }
     }
     ~Timer() { if (on) (void)hipEventRecord(ctx->timed[slot].b, s); }
+    // a launch whose matrix-pipe work per algorithmic FLOP differs from its arithmetic mode's (the Winograd form: 2/3 of it)
+    void mfma_factor(double f) { if (on) ctx->timed[slot].mfma_factor = f; }
 };
 
 double conv_flops(int h, int w, int cin, int cout, int taps) { return 2.0 * h * w * (double)cin * cout * taps; }
@@ -607,7 +610,7 @@ int batched_forward(nst_ctx* ctx, const float* const* xi, const int* lv, int n, 
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wf_bf[l]; b.bias = ctx->bias[l]; b.Cin = kCin[l]; b.Cout = kCout[l]; b.relu = 1;
         b.wt_h2 = ctx->wf_h2[l]; b.wt_h2_inv = ctx->wf_h2_inv[l]; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows; b.persist = ctx->persist;
-        b.wt_wino = ctx->wf_wino[l]; b.wt_wino_inv = ctx->wf_wino_inv[l]; b.wino_level = ctx->winograd;
+        b.wt_wino = ctx->wf_wino[l]; b.wt_wino_inv = ctx->wf_wino_inv[l];
         double flops = 0;
         for (int k = 0; k < n; ++k) {
             ActSet& a = ctx->lv[lv[k]].acts;
@@ -624,7 +627,7 @@ int batched_forward(nst_ctx* ctx, const float* const* xi, const int* lv, int n, 
         }
         {
             Timer t(ctx, s, K_CONV3, flops, b.img[0].H, b.img[0].W, b.Cin, b.Cout, 9, l);
-            if (h2 && b.wt_wino && conv_wino_eligible(b)) HIPCHK(ctx, launch_conv_wino_batch(b, s));
+            if (h2 && b.wt_wino && conv_wino_eligible(b)) { t.mfma_factor(2.0); HIPCHK(ctx, launch_conv_wino_batch(b, s)); }
             else HIPCHK(ctx, h2 ? launch_conv_h2_batch(b, s) : launch_conv_bf3_batch(b, s));
         }
         if (l == 4 && fork_sw >= 0.f && ctx->side) {
@@ -726,7 +729,7 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
         ConvBatch b{};
         b.n = n; b.wt_bf = ctx->wd_bf[l]; b.bias = nullptr; b.Cin = kCout[l]; b.Cout = kCin[l]; b.relu = 0;
         b.wt_h2 = ctx->wd_h2[l]; b.wt_h2_inv = ctx->wd_h2_inv[l]; b.mfma16 = ctx->mfma16; b.wg256 = ctx->wg256; b.tile_rows = ctx->tile_rows; b.persist = ctx->persist;
-        b.wt_wino = ctx->wd_wino[l]; b.wt_wino_inv = ctx->wd_wino_inv[l]; b.wino_level = ctx->winograd;
+        b.wt_wino = ctx->wd_wino[l]; b.wt_wino_inv = ctx->wd_wino_inv[l];
         // f16x2: when a max-pool follows layer l, cur[] holds the gradient w.r.t. the POOLED map and this launch's
         // loader un-pools it through the arg-max code (no un-pool kernel, no full-size gradient round trip)
         const int pl = pool_index_after(l);
@@ -767,7 +770,7 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
         }
         {
             Timer t(ctx, s, K_CONV3, flops, b.img[0].H, b.img[0].W, b.Cin, b.Cout, 9, -l);
-            if (h2 && !win && b.wt_wino && conv_wino_eligible(b)) HIPCHK(ctx, launch_conv_wino_batch(b, s));
+            if (h2 && !win && b.wt_wino && conv_wino_eligible(b)) { t.mfma_factor(2.0); HIPCHK(ctx, launch_conv_wino_batch(b, s)); }
             else HIPCHK(ctx, h2 ? launch_conv_h2_batch(b, s) : launch_conv_bf3_batch(b, s));
         }
         for (int k = 0; k < n; ++k) {
@@ -838,6 +841,11 @@ int fold_timed(nst_ctx* ctx) {
         HIPCHK(ctx, hipEventElapsedTime(&d, t.a, t.b));
         ctx->acc_ms[t.cls] += d;
         ctx->acc_flops[t.cls] += t.flops;
+        {
+            // f16x2: 3 MFMAs per product block, bf16x3: 6, fp32 MFMA: 1 (conv1_1 and the streaming kernels run no 16-bit MFMA)
+            const double mode = (t.cls == K_CONV3 || t.cls == K_GRAM) ? (ctx->conv_mode == 2 ? 3.0 : ctx->conv_mode == 1 ? 6.0 : 1.0) : 1.0;
+            ctx->acc_mfma[t.cls] += t.flops * (t.mfma_factor >= 0.0 ? t.mfma_factor : mode);
+        }
         ctx->acc_launches[t.cls] += 1;
     }
     ctx->timed.clear();
@@ -946,7 +954,7 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
     ctx->wg256 = (opts.h2_wg256 >= 0 ? opts.h2_wg256 : env_flag("NST_H2_WG256", 0)) ? 1 : 0;
     ctx->tile_rows = opts.h2_tile_rows >= 0 ? opts.h2_tile_rows : env_flag("NST_H2_TILE_ROWS", 0);
     ctx->persist = (opts.h2_persist >= 0 ? opts.h2_persist : env_flag("NST_H2_PERSIST", 0)) ? 1 : 0;
-    ctx->winograd = opts.h2_winograd >= 0 ? opts.h2_winograd : env_flag("NST_H2_WINOGRAD", 0);
+    ctx->winograd = (opts.h2_winograd >= 0 ? opts.h2_winograd : env_flag("NST_H2_WINOGRAD", 1)) ? 1 : 0;
     ctx->level_split = (opts.level_split >= 0 ? opts.level_split : env_flag("NST_LEVEL_SPLIT", 0)) ? 1 : 0;
     ctx->gram_overlap = (opts.gram_overlap >= 0 ? opts.gram_overlap : env_flag("NST_GRAM_OVERLAP", 0)) ? 1 : 0;
     if (ctx->use_graph && hipStreamCreateWithFlags(&ctx->gstream, hipStreamNonBlocking) != hipSuccess) { ctx->err = "stream creation failed"; return bail(NST_E_HIP); }
@@ -1467,9 +1475,17 @@ int nst_timing_totals(nst_ctx* ctx, int cls, double* ms, long* launches, double*
     else if (cls < 0) { *ms = ctx->acc_closure_ms; *launches = ctx->acc_closures; *flops = 0; }
     else { *ms = ctx->acc_ms[cls]; *launches = ctx->acc_launches[cls]; *flops = ctx->acc_flops[cls]; }
     if (reset) {
-        for (int i = 0; i < 4; ++i) { ctx->acc_ms[i] = 0; ctx->acc_flops[i] = 0; ctx->acc_launches[i] = 0; }
+        for (int i = 0; i < 4; ++i) { ctx->acc_ms[i] = 0; ctx->acc_flops[i] = 0; ctx->acc_mfma[i] = 0; ctx->acc_launches[i] = 0; }
         ctx->acc_closure_ms = 0; ctx->acc_closures = 0; ctx->acc_sampled = 0;
     }
+    return NST_OK;
+}
+
+int nst_timing_mfma_flops(nst_ctx* ctx, int cls, double* mfma_flops) {
+    NSTCHK(bind(ctx));
+    if (!mfma_flops || cls < 0 || cls >= K_NCLASS) return fail(ctx, NST_E_ARG, "bad argument");
+    NSTCHK(fold_timed(ctx));
+    *mfma_flops = ctx->acc_mfma[cls];
     return NST_OK;
 }
 

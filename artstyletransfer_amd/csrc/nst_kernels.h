@@ -96,7 +96,6 @@ struct ConvBatch {
     int total_tiles;         // conv_h2: filled by the launcher (tiles x output-channel tiles)
     const void* wt_wino;     // conv_wino: the layer's transformed weights in fragment order (nullptr: none)
     float wt_wino_inv;
-    int wino_level;          // nst_options.h2_winograd
 };
 
 // conv_wino.hip: forward 3x3 convolution as 1-D Winograd F(2,3) in the f16x2 arithmetic (nst_options.h2_winograd)

@@ -41,7 +41,7 @@ class StyleEngine:
                  h2_mfma16: Optional[bool] = None, h2_wg256: Optional[bool] = None,
                  h2_tile_rows: Optional[int] = None, gram_overlap: Optional[bool] = None,
                  h2_persist: Optional[bool] = None, level_split: Optional[bool] = None,
-                 h2_winograd: Optional[int] = None):
+                 h2_winograd: Optional[bool] = None):
         """Options (nst_options): None = environment variable (NST_CONV, NST_BATCH, NST_SINGLE_STREAM, NST_GRAPH,
         NST_H2_BAND_ROWS, NST_LBFGS_GRAM, NST_H2_MFMA16; read once, here) and otherwise the default (f16x2, batched, ...)."""
         self.lib = _lib.load()
@@ -222,6 +222,12 @@ class StyleEngine:
         _lib.check(self.ctx, self.lib.nst_timing_totals(self.ctx, cls, C.byref(ms), C.byref(n), C.byref(fl),
                                                         int(reset)), "nst_timing_totals")
         return ms.value, n.value, fl.value
+
+    def timing_mfma_flops(self, cls: int) -> float:
+        """Executed matrix-pipe FLOPs of the launches accumulated in timing_totals(cls) (read it BEFORE a resetting call)."""
+        fl = C.c_double()
+        _lib.check(self.ctx, self.lib.nst_timing_mfma_flops(self.ctx, cls, C.byref(fl)), "nst_timing_mfma_flops")
+        return fl.value
 
     # ---- standalone pieces (unit parity) ----------------------------------------------------------
     def vgg_features(self, x: torch.Tensor) -> List[torch.Tensor]:

@@ -17,7 +17,7 @@ no data-path collective, `value` is the whole-node closure rate, scaling is weak
 Beside the headline (N = 1 only, after the timed region; none of it is inside `value`):
   exact_f32        the same job on the exact fp32 MFMA (nst_options.conv_mode = f32), priced against the 157.3 TF fp32 peak;
   sustained        the headline job kept running for >= 5 s whatever --steps says, with the shader clock sampled from sysfs;
-  winograd_experiment  the same job with nst_options.h2_winograd (conv_wino.hip), a parity-tested experiment that is not the default
+  direct_convolution   the same job with nst_options.h2_winograd = 0 (no launch in the Winograd form)
   progressing_job  jobs whose image moves at every step (Adam; L-BFGS with the 25-evaluation line search), so that the
                    optimiser update with a filling curvature history is in a driver-seen number;
   cpu_baseline     the oracle timed on this box's host cores on a bounded sample of the same job.
@@ -43,7 +43,8 @@ import torch
 # so the matrix pipe executes 6x the algorithmic FLOPs and is priced against the bf16 peak.
 MFMA_PEAK = {"f32": 157.3, "bf16x3": 2500.0, "f16x2": 2500.0}
 MFMA_WORK_FACTOR = {"f32": 1.0, "bf16x3": 6.0, "f16x2": 3.0}
-MFMA_KERNEL = {"f32": "conv_mfma_kernel", "bf16x3": "conv_bf3_batch_kernel", "f16x2": "conv_h2_batch_kernel"}
+MFMA_KERNEL = {"f32": "conv_mfma_kernel", "bf16x3": "conv_bf3_batch_kernel",
+               "f16x2": "conv_h2_batch_kernel + conv_wino_batch_kernel (the 14 of 24 launches with Cin >= 256 and no second source as Winograd F(2,3))"}
 MFMA_DTYPE = {"f32": "f32",
               "bf16x3": "bf16 (3 exact pieces per fp32 operand, 6 MFMAs per product, fp32 accumulate)",
               "f16x2": "f16 (2 scaled pieces per fp32 operand = 22 significand bits, 3 MFMAs per product, main and "
@@ -138,14 +139,20 @@ class GpuSampler:
         return out or None
 
 
-def mfma_roofline(mode, algorithmic_flops, ms, launches, extra=None):
+def mfma_roofline(mode, algorithmic_flops, ms, launches, extra=None, mfma_flops=None):
+    """`mfma_flops`: the executed matrix-pipe FLOPs of those launches (nst_timing_mfma_flops: the arithmetic's MFMAs per
+    product, 2/3 of them where a launch ran as Winograd F(2,3)); None = algorithmic x the arithmetic's factor."""
     alg = algorithmic_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    hw = alg * MFMA_WORK_FACTOR[mode]
+    hw = alg * MFMA_WORK_FACTOR[mode] if mfma_flops is None else (mfma_flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0)
     out = {"bound": "mfma", "kernel": MFMA_KERNEL[mode],
            "what": "3x3 conv forward + input gradient (+ fused Gram backward)",
            "mfma_dtype": MFMA_DTYPE[mode],
            "achieved": hw, "peak": MFMA_PEAK[mode], "unit": "TFLOP/s", "frac": hw / MFMA_PEAK[mode],
-           "algorithmic_tflops": alg, "mfma_work_factor": MFMA_WORK_FACTOR[mode],
+           "algorithmic_tflops": alg, "mfma_work_factor": (hw / alg) if alg > 0 else MFMA_WORK_FACTOR[mode],
+           # what the same outputs cost as DIRECT convolutions in this arithmetic (3 MFMAs per product for f16x2): the rate
+           # comparable with the records of the builds before the Winograd launches existed
+           "direct_equivalent_tflops": alg * MFMA_WORK_FACTOR[mode],
+           "direct_equivalent_frac": alg * MFMA_WORK_FACTOR[mode] / MFMA_PEAK[mode],
            # NOT a roofline fraction: how many times the fp32-MFMA peak RATE (157.3 TF) the algorithmic rate is
            "algorithmic_rate_over_fp32_mfma_peak_rate": alg / MFMA_PEAK["f32"],
            # tools/micro/mfma_power.hip on this pool, random fp16 operands: MFMA-only kernel 1 680 TFLOP/s (zeros: 2 460),
@@ -507,7 +514,7 @@ def main():
             gms, gn, gfl = eng.timing_totals(1)
             oms, on, _ = eng.timing_totals(3)
             c1ms, c1n, c1fl = eng.timing_totals(2)
-            out["roofline"] = mfma_roofline(eng.conv_mode(), fl, ms, n)
+            out["roofline"] = mfma_roofline(eng.conv_mode(), fl, ms, n, mfma_flops=eng.timing_mfma_flops(0))
             if args.levels == 3 and eng.conv_mode() == "f16x2" and not sharded:
                 out["roofline"]["traffic_from_committed_profile"] = committed_traffic_per_launch("conv_h2")
             _, sampled, _ = eng.timing_totals(-2)
@@ -550,13 +557,13 @@ def main():
             ol.close()
             el.close()
             out["progressing_job"] = prog
-            # ---- the experimental Winograd F(2,3) path on the same job (nst_options.h2_winograd; not in `value`)
-            wg, ew, ow, _ = side_job(args, args.optimizer, args.lbfgs_max_eval, 20 * per_step, 2 * per_step, h2_winograd=True)
+            # ---- the same job with every convolution direct (nst_options.h2_winograd = 0: the build of the rounds before)
+            wg, ew, ow, _ = side_job(args, args.optimizer, args.lbfgs_max_eval, 20 * per_step, 2 * per_step, h2_winograd=False)
             ow.close()
             ew.close()
-            wg["what"] = ("the same job with the plain Cin >= 256 conv launches (10 of 24) as a 1-D Winograd F(2,3) in the same "
-                          "f16x2 arithmetic (conv_wino.hip): 1.5x fewer MFMAs there; parity-tested, not the default")
-            out["winograd_experiment"] = wg
+            wg["what"] = ("the same job with nst_options.h2_winograd = 0: all 24 conv launches as direct convolutions "
+                          "(3 f16 MFMAs per product everywhere)")
+            out["direct_convolution"] = wg
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(job_host, cfg, args.cpu_closures)
         print(json.dumps(out), flush=True)

@@ -95,11 +95,11 @@ typedef struct nst_options {
     int level_split;      /* f16x2 batched closure: 1 = the top pyramid level's chain on the caller's stream and the lower levels'
                              chain on a side stream of the context, joined before the gradients are merged; 0 = one launch per
                              layer over all levels; -1: env NST_LEVEL_SPLIT, default 0 */
-    int h2_winograd;      /* f16x2 batched closure, EXPERIMENT: 1 = the forward launches with Cin >= 128, Cout a multiple of 128 and
-                             no pooling behind them (conv3_2, conv3_3, conv4_1 ... conv4_3, conv5_1) run as a 1-D Winograd F(2,3)
-                             along x (conv_wino.hip: 1.5x fewer MFMAs, a few 1e-7 of extra rounding in those feature maps);
-                             2 = also the input-gradient launches that un-pool (slower there); 0 = direct convolution everywhere;
-                             -1: env NST_H2_WINOGRAD, default 0 */
+    int h2_winograd;      /* f16x2 batched closure: 1 = the forward and input-gradient launches with Cin >= 256 and Cout a
+                             multiple of 128 that have no second (Gram) source - 14 of the 24 of a closure - run as a 1-D Winograd
+                             F(2,3) along x (conv_wino.hip: 1.5x fewer MFMAs there; the feature maps are no further from an fp64
+                             evaluation than the direct path's); 0 = direct convolution everywhere;
+                             -1: env NST_H2_WINOGRAD, default 1 */
 } nst_options;
 void nst_options_default(nst_options* opts);
 int nst_ctx_create_ex(int device, const float* const* weights, const float* const* biases, const nst_options* opts,
@@ -299,6 +299,9 @@ int nst_last_closure_class(nst_ctx* ctx, int cls, float* ms, int* launches, doub
 /* the same accumulated over every closure since the last reset (timing mode 2); cls = -1: whole
  * closures (ms = summed closure time on the caller's stream, launches = closures). */
 int nst_timing_totals(nst_ctx* ctx, int cls, double* ms, long* launches, double* flops, int reset);
+/* executed matrix-pipe FLOPs of the launches accumulated in nst_timing_totals(cls): algorithmic FLOPs x the MFMAs the
+ * arithmetic spends per product (f16x2: 3, bf16x3: 6, f32: 1), x 2/3 for the launches that ran as Winograd F(2,3). */
+int nst_timing_mfma_flops(nst_ctx* ctx, int cls, double* mfma_flops);
 /* debugging aid: prints one line per timed launch of the last closure (timing mode 2) to stderr */
 int nst_dump_last_closure(nst_ctx* ctx);
 

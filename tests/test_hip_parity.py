@@ -285,8 +285,18 @@ def test_closure_execution_modes_agree(eng, vgg_weights, opts):
         for _ in range(3 if opts.get("use_graph") else 1):     # same buffers again: captured on the 2nd call, replayed on the 3rd
             g1, l1 = other.closure(x, CW, SW, TVW, g1, l1)
         np.testing.assert_allclose(l1.cpu().numpy(), l0.cpu().numpy(), rtol=1e-5, atol=1e-7)
-        if "conv_mode" not in opts:                              # same arithmetic, another schedule: same decisions
-            assert rel_l2(g1.cpu().numpy(), g0.cpu().numpy()) < 1e-5
+        if "conv_mode" not in opts:
+            # same arithmetic AND the same kernels on another schedule: same decisions.  The per-level schedules run every
+            # convolution direct, so their twin is the batched closure with the Winograd launches off.
+            twin = eng if opts.get("use_graph") else StyleEngine(vgg_weights, 0, h2_winograd=False)
+            try:
+                if twin is not eng:
+                    _setup(twin, c, s)
+                gt, _ = twin.closure(x, CW, SW, TVW)
+                assert rel_l2(g1.cpu().numpy(), gt.cpu().numpy()) < 1e-5
+            finally:
+                if twin is not eng:
+                    twin.close()
     finally:
         other.close()
 
@@ -353,11 +363,11 @@ def test_experiment_switches_agree_with_the_default(vgg_weights, opts):
         np.testing.assert_allclose(l1, l0, rtol=1e-5)
 
 
-@pytest.mark.parametrize("level", [1, 2])
 @pytest.mark.parametrize("h,w,nlev", [(128, 192, 2), (200, 280, 3), (72, 100, 2)])
-def test_winograd_forward_vs_oracle(vgg_weights, h, w, nlev, level):
-    """nst_options.h2_winograd (conv_wino.hip: the forward convolutions with Cin >= 256 and no pooling behind them as a 1-D
-    Winograd F(2,3) in the f16x2 arithmetic) against the ORACLE like every other schedule: losses 1e-5, the whole gradient
+def test_winograd_forward_vs_oracle(vgg_weights, h, w, nlev):
+    """nst_options.h2_winograd (conv_wino.hip: the forward and input-gradient convolutions with Cin >= 256 and no second
+    source as a 1-D Winograd F(2,3) in the f16x2 arithmetic, pooling epilogue and un-pooling loader included) against the
+    ORACLE like every other schedule: losses 1e-5, the whole gradient
     2e-5 under the device pass's own ReLU / pooling / TV-sign decisions, per loss term; edge tiles (280 = 17.5 x 16 columns,
     200 = 25 x 8 rows, 100 and 72 not multiples of the tile) included; and the feature maps against an fp64 evaluation no
     further off than torch's fp32 ones by more than the bound the direct path is held to."""
@@ -365,10 +375,10 @@ def test_winograd_forward_vs_oracle(vgg_weights, h, w, nlev, level):
     c, s = _levels(h, w, nlev, 41), _levels(h - 16, w + 8, nlev, 42)
     xt = cpu_ref.prepare_img((0.7 * c[0] + 0.3 * cpu_ref.synthetic_image(h, w, seed=43)).astype(np.float32))
     tg = oracle_targets(c, s, vgg_weights)
-    e = StyleEngine(vgg_weights, 0, h2_winograd=level)      # (2: also the un-pooling input-gradient launches)
+    e = StyleEngine(vgg_weights, 0, h2_winograd=True)
     try:
         _setup(e, c, s)
-        closure_vs_oracle_under_equal_decisions(e, xt, tg, vgg_weights, f"winograd level {level} {h}x{w} L{nlev - 1}")
+        closure_vs_oracle_under_equal_decisions(e, xt, tg, vgg_weights, f"winograd {h}x{w} L{nlev - 1}")
         e.closure(dev(xt), CW, SW, TVW)
         acts = e.level_activations(0)
         w64 = [(a.double(), b.double()) for a, b in vgg_weights]
@@ -401,10 +411,10 @@ def test_options_default_to_the_environment(vgg_weights, monkeypatch):
                                  (89, 320, 2, 89, 320), (290, 32, 2, 290, 32), (336, 77, 3, 104, 271)])
 def test_random_geometries_vs_oracle(vgg_weights, geo):
     """Odd sizes, foreign-size styles, 1-3 levels (geometries drawn by tools/fuzz_modes.py, which ran 40 of them): the
-    default closure (fp16-piece convolutions, batched levels, fused un-pooling, buffer-addressed epilogues on interior
-    tiles and the general form on edge tiles), the exact-f32-MFMA closure on the per-level schedule, and the f16x2
-    per-level launches in 16-row bands - each against the oracle under equal decisions (gradient 2e-5 on the whole).  An
-    indexing bug shows as errors of order 1."""
+    default closure (fp16-piece convolutions, batched levels, Winograd launches where they apply, fused un-pooling,
+    buffer-addressed epilogues on interior tiles and the general form on edge tiles), the same with every convolution
+    direct, the exact-f32-MFMA closure on the per-level schedule, and the f16x2 per-level launches in 16-row bands - each
+    against the oracle under equal decisions (gradient 2e-5 on the whole).  An indexing bug shows as errors of order 1."""
     from artstyletransfer_amd.engine import StyleEngine
     h, w, nlev, hs, ws = geo
     c, s = _levels(h, w, nlev, 1), _levels(hs, ws, nlev, 2)
@@ -412,8 +422,9 @@ def test_random_geometries_vs_oracle(vgg_weights, geo):
     tg = oracle_targets(c, s, vgg_weights)
     res = []
     for opts in (dict(conv_mode="f32", batched=False, h2_band_rows=0),
-                 dict(conv_mode="f16x2", batched=True, h2_band_rows=0),
-                 dict(conv_mode="f16x2", batched=False, h2_band_rows=16)):      # per-level launches in 16-row bands
+                 dict(conv_mode="f16x2", batched=True, h2_band_rows=0, h2_winograd=False),       # every convolution direct
+                 dict(conv_mode="f16x2", batched=False, h2_band_rows=16),      # per-level launches in 16-row bands (direct)
+                 dict(conv_mode="f16x2", batched=True, h2_band_rows=0)):       # the default: Winograd launches where they apply
         e = StyleEngine(vgg_weights, 0, **opts)
         try:
             _setup(e, c, s)
@@ -432,7 +443,7 @@ def test_random_geometries_vs_oracle(vgg_weights, geo):
         np.testing.assert_allclose(l1[-1], l0[-1], rtol=1e-5)
         np.testing.assert_allclose(l1[:-1].reshape(nlev, 4)[:, 0], l0[:-1].reshape(nlev, 4)[:, 0], rtol=2e-5)
         assert np.isfinite(g1).all()
-    # the banded per-level launches compute what the batched launches compute
+    # the banded per-level launches compute what the batched launches of the same (direct) kernel compute
     np.testing.assert_allclose(res[2][1], res[1][1], rtol=1e-6)
     assert rel_l2(res[2][0], res[1][0]) < 1e-5
 
