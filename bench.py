@@ -70,7 +70,7 @@ def committed_traffic_per_launch(kernel_prefix):
             continue
         n = b = 0
         for kname, e in kernels.items():
-            if kname.startswith(kernel_prefix):
+            if any(kname.startswith(pfx) for pfx in kernel_prefix.split("|")):
                 n += e["launches"]
                 b += e["fetch_bytes_corrected"] + e["write_bytes"]
         if n:
@@ -516,7 +516,7 @@ def main():
             c1ms, c1n, c1fl = eng.timing_totals(2)
             out["roofline"] = mfma_roofline(eng.conv_mode(), fl, ms, n, mfma_flops=eng.timing_mfma_flops(0))
             if args.levels == 3 and eng.conv_mode() == "f16x2" and not sharded:
-                out["roofline"]["traffic_from_committed_profile"] = committed_traffic_per_launch("conv_h2")
+                out["roofline"]["traffic_from_committed_profile"] = committed_traffic_per_launch("conv_h2|conv_wino")
             _, sampled, _ = eng.timing_totals(-2)
             out["roofline"]["sampled_closures"] = sampled
             out["kernel_ms_per_closure"] = {"closure": cms / max(cn, 1), "conv3x3_mfma": ms / max(sampled, 1)}

@@ -85,14 +85,14 @@ def traffic(fetch_dir, write_dir, out_txt, out_json):
 def mfma(directory, out_txt):
     rows = rows_of(directory)
     vals, meta = per_dispatch(rows)
-    lines = ["# MFMA utilisation of the batched 3x3 conv launches (conv_h2_batch_kernel / conv_bf3_batch_kernel), one L=2 closure",
+    lines = ["# MFMA utilisation of the batched 3x3 conv launches (conv_h2_batch_kernel / conv_wino_batch_kernel / conv_bf3_batch_kernel), one L=2 closure",
              "# rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY",
              "#   --output-format csv -- python tools/pmc_run.py 3 2",
              "# mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE/8 * 256 CU * 4 SIMD); clk ~ GRBM_GUI_ACTIVE/8/duration"]
     busy_sum = cyc_sum = 0.0
     for d in last_closure(rows):
         m = meta[d]
-        if "conv_bf3" not in m["Kernel_Name"] and "conv_h2" not in m["Kernel_Name"]:
+        if "conv_bf3" not in m["Kernel_Name"] and "conv_h2" not in m["Kernel_Name"] and "conv_wino" not in m["Kernel_Name"]:
             continue
         v = vals[d]
         dur = (int(m["End_Timestamp"]) - int(m["Start_Timestamp"])) / 1e3
