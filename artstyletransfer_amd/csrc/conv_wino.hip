@@ -39,11 +39,11 @@ constexpr int W_ROWB = 144;                              // 32 channels x 2 piec
 constexpr int W_PROWB = 4 * W_PAIRS * W_ROWB + 128;      // a patch row: [xi][pair] entries; + 128 B: rows y and y + 1 of a fragment
                                                          // (16 lanes = 2 rows x 8 pairs) land on complementary 16-byte slots
 constexpr int W_A_BYTES = W_PH * W_PROWB;
-constexpr int W_E_BYTES = 4 * 64 * 64 * 4;               // epilogue: m[xi][pair row][64 channels] fp32
-constexpr int W_BITS_OFF = W_E_BYTES;                    // + 128 pixels x 2 ReLU-mask words
-constexpr int W_CODE_OFF = W_BITS_OFF + 128 * 2 * 4;     // + 32 pooled pixels x 2 words x 4 window positions
-constexpr int W_LDS = 2 * W_A_BYTES;
-static_assert(W_CODE_OFF + 32 * 2 * 4 * 4 <= W_LDS, "the epilogue reuses the patch buffers");
+constexpr int W_E_BYTES = 4 * 64 * 128 * 4;              // epilogue: m[xi][pair row][128 channels] fp32
+constexpr int W_BITS_OFF = W_E_BYTES;                    // + 128 pixels x 4 ReLU-mask words
+constexpr int W_CODE_OFF = W_BITS_OFF + 128 * 4 * 4;     // + 32 pooled pixels x 4 words x 4 window positions
+constexpr int W_LDS = W_CODE_OFF + 32 * 4 * 4 * 4;       // 135 KB (the K loop uses the first 2 x W_A_BYTES = 92.5 KB of it)
+static_assert(2 * W_A_BYTES <= W_LDS && W_LDS <= 160 * 1024, "LDS budget");
 constexpr float LO_UP = 2048.f, LO_DOWN = 1.f / 2048.f;
 
 __device__ __forceinline__ void cut2x4(const f32x4 v, const float s, u32x2& hi, u32x2& lo) {
@@ -288,38 +288,36 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     // ---- epilogue: the four xi accumulators of every pair meet in LDS, one output-channel half at a time.  A thread then
     // owns a 2x2 pixel window (image rows 2 yp, 2 yp + 1 of the tile, output pair p) x 4 channels: output transform, bias /
     // addend, ReLU / ReLU mask, 16-byte stores, and - where a pooling layer follows - the window's maximum and arg-max code.
-    float* E = reinterpret_cast<float*>(smem);                               // [xi][pair row 64][64]
-    unsigned* WB = reinterpret_cast<unsigned*>(smem + W_BITS_OFF);           // [pixel 128][2 words]
-    unsigned* PC = reinterpret_cast<unsigned*>(smem + W_CODE_OFF);           // [pooled pixel 32][2 words][4 positions]
+    float* E = reinterpret_cast<float*>(smem);                               // [xi][pair row 64][128]
+    unsigned* WB = reinterpret_cast<unsigned*>(smem + W_BITS_OFF);           // [pixel 128][4 words]
+    unsigned* PC = reinterpret_cast<unsigned*>(smem + W_CODE_OFF);           // [pooled pixel 32][4 words][4 positions]
     const int words = Cout >> 5;
     float amax = 0.f;
     const int yp = tid >> 7, p = (tid >> 4) & 7, cq = tid & 15;
-    for (int pass = 0; pass < 2; ++pass) {
-        if (wn == pass) {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int m = (r & 3) + 8 * (r >> 2) + 4 * half;      // row of the 32-row tile
-                        E[(xi * 64 + mt * 32 + m) * 64 + nt * 32 + l31] = fmaf(accx[mt][nt][r], LO_DOWN, accm[mt][nt][r]) * inv;
-                    }
-        }
-        if (im.bits_out && tid < 256) WB[tid] = 0u;
-        if (im.pcode_out && tid >= 256) PC[tid - 256] = 0u;
-        __syncthreads();
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * half;      // row of the 32-row tile
+                E[(xi * 64 + mt * 32 + m) * 128 + wn * 64 + nt * 32 + l31] = fmaf(accx[mt][nt][r], LO_DOWN, accm[mt][nt][r]) * inv;
+            }
+    if (im.bits_out) WB[tid] = 0u;
+    if (im.pcode_out) PC[tid] = 0u;
+    __syncthreads();
+    for (int pass = 0; pass < 2; ++pass) {      // the two 64-channel halves of the tile, one after the other per thread
         const int co = n0 + pass * 64 + cq * 4;
         const f32x4 bv = b.bias ? *reinterpret_cast<const f32x4*>(b.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
-        const int w = cq >> 3, sh = (cq & 7) * 4;
+        const int w = pass * 2 + (cq >> 3), sh = (cq & 7) * 4;
         f32x4 win[2][2];                  // [row of the window][column]
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int yy = 2 * yp + k, pr = yy * 8 + p;
-            const f32x4 m0 = *reinterpret_cast<const f32x4*>(E + (0 * 64 + pr) * 64 + cq * 4);
-            const f32x4 m1 = *reinterpret_cast<const f32x4*>(E + (1 * 64 + pr) * 64 + cq * 4);
-            const f32x4 m2 = *reinterpret_cast<const f32x4*>(E + (2 * 64 + pr) * 64 + cq * 4);
-            const f32x4 m3 = *reinterpret_cast<const f32x4*>(E + (3 * 64 + pr) * 64 + cq * 4);
+            const f32x4 m0 = *reinterpret_cast<const f32x4*>(E + (0 * 64 + pr) * 128 + pass * 64 + cq * 4);
+            const f32x4 m1 = *reinterpret_cast<const f32x4*>(E + (1 * 64 + pr) * 128 + pass * 64 + cq * 4);
+            const f32x4 m2 = *reinterpret_cast<const f32x4*>(E + (2 * 64 + pr) * 128 + pass * 64 + cq * 4);
+            const f32x4 m3 = *reinterpret_cast<const f32x4*>(E + (3 * 64 + pr) * 128 + pass * 64 + cq * 4);
             f32x4 ya = m0 + m1 + m2 + bv, yb = m1 - m2 - m3 + bv;
             const int gy = y0 + yy, gx = x0 + 2 * p;
             const bool ina = gy < H && gx < W, inb = gy < H && gx + 1 < W;
@@ -350,8 +348,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
             if (inb) *reinterpret_cast<f32x4*>(im.out + (pa + 1) * Cout + co) = yb;
             if (im.bits_out) {
                 const int pix = yy * 16 + 2 * p;
-                atomicOr(&WB[pix * 2 + w], na << sh);
-                atomicOr(&WB[(pix + 1) * 2 + w], nb << sh);
+                atomicOr(&WB[pix * 4 + w], na << sh);
+                atomicOr(&WB[(pix + 1) * 4 + w], nb << sh);
             }
             win[k][0] = ya; win[k][1] = yb;
         }
@@ -378,22 +376,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
             if (inw) *reinterpret_cast<f32x4*>(im.pool_out + ((size_t)py * PW2 + px) * Cout + co) = mx;
             if (im.pcode_out) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) atomicOr(&PC[((yp * 8 + p) * 2 + w) * 4 + q], cn[q] << sh);
+                for (int q = 0; q < 4; ++q) atomicOr(&PC[((yp * 8 + p) * 4 + w) * 4 + q], cn[q] << sh);
             }
         }
-        __syncthreads();          // (E may be overwritten by the next pass; the mask and code words are complete)
-        if (im.bits_out || im.pcode_out) {
-            if (im.bits_out && tid < 256) {
-                const int pix = tid >> 1, w2 = tid & 1;
-                const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
-                if (gy < H && gx < W) im.bits_out[((size_t)gy * W + gx) * words + (n0 >> 5) + pass * 2 + w2] = WB[tid];
-            }
-            if (im.pcode_out && tid >= 256) {
-                const int i = tid - 256, pp = i >> 3, w2 = (i >> 2) & 1, q = i & 3;
-                const int qy = (y0 >> 1) + (pp >> 3), qx = (x0 >> 1) + (pp & 7);
-                if (qy < PH2 && qx < PW2) im.pcode_out[(((size_t)qy * PW2 + qx) * words + (n0 >> 5) + pass * 2 + w2) * 4 + q] = PC[i];
-            }
-            __syncthreads();
+    }
+    if (im.bits_out || im.pcode_out) {
+        __syncthreads();          // the mask and code words are complete
+        if (im.bits_out) {
+            const int pix = tid >> 2, w2 = tid & 3;
+            const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
+            if (gy < H && gx < W) im.bits_out[((size_t)gy * W + gx) * words + (n0 >> 5) + w2] = WB[tid];
+        }
+        if (im.pcode_out) {
+            const int pp = tid >> 4, w2 = (tid >> 2) & 3, q = tid & 3;
+            const int qy = (y0 >> 1) + (pp >> 3), qx = (x0 >> 1) + (pp & 7);
+            if (qy < PH2 && qx < PW2) im.pcode_out[(((size_t)qy * PW2 + qx) * words + (n0 >> 5) + w2) * 4 + q] = PC[tid];
         }
     }
     if (im.amax_out) {
