@@ -393,6 +393,33 @@ def test_winograd_forward_vs_oracle(vgg_weights, h, w, nlev):
         e.close()
 
 
+def test_executed_mfma_work_accounting(vgg_weights):
+    """nst_timing_mfma_flops: the matrix-pipe FLOPs the timed conv launches executed - 3 per algorithmic FLOP in the f16x2
+    arithmetic, 2 in the launches that ran as Winograd F(2,3) (what bench.py's roofline divides by the launch time)."""
+    from artstyletransfer_amd.engine import StyleEngine
+    c, s = _levels(256, 384, 2, 51), _levels(256, 384, 2, 52)
+    x = dev(cpu_ref.prepare_img(c[0]))
+    got = {}
+    for wino in (False, True):
+        e = StyleEngine(vgg_weights, 0, h2_winograd=wino)
+        try:
+            _setup(e, c, s)
+            e.closure(x, CW, SW, TVW)
+            e.set_timing(2)
+            e.timing_totals(0, reset=True)
+            e.closure(x, CW, SW, TVW)
+            torch.cuda.synchronize()
+            ms, n, alg = e.timing_totals(0)
+            got[wino] = (n, alg, e.timing_mfma_flops(0))
+        finally:
+            e.close()
+    (n0, alg0, ex0), (n1, alg1, ex1) = got[False], got[True]
+    assert n0 == n1 == 24 and alg0 == alg1 > 0
+    assert ex0 == pytest.approx(3.0 * alg0, rel=1e-12)
+    # conv3_2 ... conv5_1 forward and the seven input-gradient launches of that size: more than half of the FLOPs
+    assert 2.2 * alg1 < ex1 < 2.6 * alg1
+
+
 def test_options_default_to_the_environment(vgg_weights, monkeypatch):
     """nst_options fields left at -1 take the environment, read once at context creation; an explicit option wins."""
     from artstyletransfer_amd.engine import StyleEngine
