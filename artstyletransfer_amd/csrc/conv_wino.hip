@@ -221,7 +221,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     // B: 16-byte units [ct][chunk][ky][wave][ks][nt][piece][lane]
     struct BF { f16x8 v[2][2]; };       // [n tile][piece]
     auto load_b = [&](BF& f, int chunk, int ky, int ks) {
+#ifdef NST_WINO_ABLATE_WEIGHTS      // timing-only build (wrong results): every stage reads the first 64 KB of the image - cache-hot
+        const int soff = ((wave * 2 + ks) * 4 * 64) * 16 + 0 * (ct + chunk + ky);
+#else
         const int soff = (((((ct * nch + chunk) * 3 + ky) * 8 + wave) * 2 + ks) * 4 * 64) * 16;
+#endif
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
