@@ -264,6 +264,40 @@ void make_bf3(const float* w, int taps, int rows, int K, std::vector<uint16_t>& 
             }
 }
 
+// fp32 <-> fp16 on the host with integer arithmetic (round to nearest even, subnormals, overflow to infinity: bit-identical to
+// the compiler's _Float16 conversions over 4e7 random values) - without F16C code generation those go through a soft-float
+// call each, and a context converts ~1e8 weights: 0.5 s of its 0.8 s creation.
+static inline uint16_t f32_to_f16(float f) {
+    uint32_t x; std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7FFFFFFFu;
+    uint32_t o;
+    if (x >= 0x47800000u) {                      // >= 65536 (rounds to infinity), infinity, NaN
+        o = (x > 0x7F800000u) ? 0x7E00u : 0x7C00u;
+    } else if (x < 0x38800000u) {                // < 2^-14: a half subnormal or zero: round(f * 2^24) through a float add
+        float a; std::memcpy(&a, &x, 4);
+        const uint32_t magic_bits = (uint32_t)((127 - 15) + (23 - 10) + 1) << 23;
+        float magic; std::memcpy(&magic, &magic_bits, 4);
+        a += magic;
+        uint32_t ab; std::memcpy(&ab, &a, 4);
+        o = ab - magic_bits;
+    } else {                                     // normal: re-bias the exponent, round to nearest even on bit 13
+        const uint32_t odd = (x >> 13) & 1u;
+        x += 0xC8000FFFu + odd;
+        o = x >> 13;
+    }
+    return (uint16_t)(sign | o);
+}
+static inline float f16_to_f32(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3FFu;
+    uint32_t b;
+    if (e == 0) { const float f = (float)m * 5.9604644775390625e-8f; std::memcpy(&b, &f, 4); b |= sign; }
+    else if (e == 31) b = sign | 0x7F800000u | (m << 13);
+    else b = sign | ((e + 112u) << 23) | (m << 13);
+    float r; std::memcpy(&r, &b, 4);
+    return r;
+}
+
 // w: [taps][rows][K] fp32  ->  out: [taps][rows][K/kc][2][kc] fp16 pieces of w * s, s = the power of two that
 // brings the largest |w| into [2^14, 2^15); *inv = 1 / s (same cut as conv_h2.hip::cut2x4).  kc = channels per K
 // chunk of the kernel shape that consumes these weights: 32 when `rows` (its output channels) is a multiple of
@@ -283,10 +317,8 @@ void make_h2(const float* w, int taps, int rows, int K, std::vector<uint16_t>& o
         for (int r = 0; r < rows; ++r)
             for (int k = 0; k < K; ++k) {
                 const float x = w[((size_t)t * rows + r) * K + k] * s;
-                const _Float16 hi = (_Float16)x;
-                const _Float16 lo = (_Float16)((x - (float)hi) * 2048.f);
-                uint16_t uh, ul;
-                std::memcpy(&uh, &hi, 2); std::memcpy(&ul, &lo, 2);
+                const uint16_t uh = f32_to_f16(x);
+                const uint16_t ul = f32_to_f16((x - f16_to_f32(uh)) * 2048.f);
                 const size_t base = (((size_t)t * rows + r) * nch + k / kc) * 2 * kc + (k % kc);
                 out[base] = uh; out[base + kc] = ul;
             }
@@ -299,18 +331,29 @@ void make_h2(const float* w, int taps, int rows, int K, std::vector<uint16_t>& o
 // channels chunk*32 + kstep*16 + 8 h .. + 7 of output channel ct*128 + wn*64 + ntile*32 + r.
 void make_wino(const float* w, int rows, int K, std::vector<uint16_t>& out, float* inv) {
     const int nct = rows / 128, nch = K / 32;
-    auto u_of = [&](int ky, int x, int o, int c) -> double {
-        const double g0 = w[((size_t)(ky * 3 + 0) * rows + o) * K + c], g1 = w[((size_t)(ky * 3 + 1) * rows + o) * K + c],
-                     g2 = w[((size_t)(ky * 3 + 2) * rows + o) * K + c];
-        return x == 0 ? g0 : x == 1 ? 0.5 * (g0 + g1 + g2) : x == 2 ? 0.5 * (g0 - g1 + g2) : g2;
-    };
-    double mx = 0.0;
+    // the transformed taps once, [ky][xi][Cout][Cin], and their largest magnitude
+    std::vector<float> U((size_t)12 * rows * K);
+    float mx = 0.f;
     for (int ky = 0; ky < 3; ++ky)
-        for (int x = 0; x < 4; ++x)
-            for (int o = 0; o < rows; ++o)
-                for (int c = 0; c < K; ++c) mx = std::max(mx, std::fabs(u_of(ky, x, o, c)));
+        for (int o = 0; o < rows; ++o) {
+            const float* g0 = w + ((size_t)(ky * 3 + 0) * rows + o) * K;
+            const float* g1 = w + ((size_t)(ky * 3 + 1) * rows + o) * K;
+            const float* g2 = w + ((size_t)(ky * 3 + 2) * rows + o) * K;
+            float* u0 = U.data() + ((size_t)(ky * 4 + 0) * rows + o) * K;
+            float* u1 = U.data() + ((size_t)(ky * 4 + 1) * rows + o) * K;
+            float* u2 = U.data() + ((size_t)(ky * 4 + 2) * rows + o) * K;
+            float* u3 = U.data() + ((size_t)(ky * 4 + 3) * rows + o) * K;
+            for (int c = 0; c < K; ++c) {
+                const double a = g0[c], b = g1[c], d = g2[c];
+                u0[c] = (float)a;
+                u1[c] = (float)(0.5 * (a + b + d));
+                u2[c] = (float)(0.5 * (a - b + d));
+                u3[c] = (float)d;
+                mx = std::max(std::max(mx, std::fabs(u0[c])), std::max(std::fabs(u1[c]), std::max(std::fabs(u2[c]), std::fabs(u3[c]))));
+            }
+        }
     int ex = 0;
-    if (mx > 0.0) (void)std::frexp(mx, &ex);
+    if (mx > 0.f) (void)std::frexp(mx, &ex);
     const float s = std::ldexp(1.f, 15 - ex);
     *inv = std::ldexp(1.f, ex - 15);
     out.assign((size_t)nct * nch * 3 * 8 * 2 * 2 * 2 * 64 * 8, 0);
@@ -319,22 +362,22 @@ void make_wino(const float* w, int rows, int K, std::vector<uint16_t>& out, floa
             for (int ky = 0; ky < 3; ++ky)
                 for (int wave = 0; wave < 8; ++wave)
                     for (int ks = 0; ks < 2; ++ks)
-                        for (int nt = 0; nt < 2; ++nt)
+                        for (int nt = 0; nt < 2; ++nt) {
+                            const int x = wave & 3, wn = wave >> 2;
+                            const size_t unit0 = ((((((size_t)(ct * nch + ch) * 3 + ky) * 8 + wave) * 2 + ks) * 2 + nt) * 2) * 64;
                             for (int lane = 0; lane < 64; ++lane) {
-                                const int x = wave & 3, wn = wave >> 2, r = lane & 31, h = lane >> 5;
+                                const int r = lane & 31, h = lane >> 5;
                                 const int o = ct * 128 + wn * 64 + nt * 32 + r;
-                                const size_t unit = ((((((size_t)(ct * nch + ch) * 3 + ky) * 8 + wave) * 2 + ks) * 2 + nt) * 2) * 64 + lane;
+                                const float* src = U.data() + ((size_t)(ky * 4 + x) * rows + o) * K + ch * 32 + ks * 16 + 8 * h;
+                                uint16_t* hi_dst = out.data() + (unit0 + lane) * 8;             // piece 0
+                                uint16_t* lo_dst = out.data() + (unit0 + 64 + lane) * 8;        // piece 1
                                 for (int j = 0; j < 8; ++j) {
-                                    const int c = ch * 32 + ks * 16 + 8 * h + j;
-                                    const float v = (float)u_of(ky, x, o, c) * s;
-                                    const _Float16 hi = (_Float16)v;
-                                    const _Float16 lo = (_Float16)((v - (float)hi) * 2048.f);
-                                    uint16_t uh, ul;
-                                    std::memcpy(&uh, &hi, 2); std::memcpy(&ul, &lo, 2);
-                                    out[unit * 8 + j] = uh;                      // piece 0
-                                    out[(unit + 64) * 8 + j] = ul;               // piece 1
+                                    const float v = src[j] * s;
+                                    hi_dst[j] = f32_to_f16(v);
+                                    lo_dst[j] = f32_to_f16((v - f16_to_f32(hi_dst[j])) * 2048.f);
                                 }
                             }
+                        }
 }
 
 int pool_index_after(int l) {
@@ -992,7 +1035,7 @@ int nst_ctx_create_ex(int device, const float* const* weights, const float* cons
                 for (int c = 0; c < ci; ++c) tmp[((size_t)t * co + o) * ci + c] = W[((size_t)o * ci + c) * 9 + t];
         if (dev_alloc_t(ctx, &ctx->wf[l], n) != NST_OK) return bail(NST_E_NOMEM);
         if (hipMemcpy(ctx->wf[l], tmp.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "weight upload failed"; return bail(NST_E_HIP); }
-        // the 16-bit-piece copy of the active arithmetic only (a context is created per job: 0.2 s and 80 MB each)
+        // the 16-bit-piece copy of the active arithmetic only (a context is created per job: 0.24 s - tools/time_ctx_create.py - and ~200 MB of weight images)
         if (ctx->conv_mode == 1) {
             make_bf3(tmp.data(), 9, co, ci, tmp16);
             if (dev_alloc(ctx, &ctx->wf_bf[l], tmp16.size() * 2) != NST_OK) return bail(NST_E_NOMEM);
