@@ -258,6 +258,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     }
     __syncthreads();
     read_a(A[0], smem, 0, 0);
+    // (as in conv_h2.hip: the later-dispatched half of the workgroup loses issue arbitration to the older half at the start of
+    // every stage; one s_setprio for that half, wave-uniform condition)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
 
     // ---- K loop: per chunk 3 stages (ky) of 2 k-steps; k-step q of the chunk multiplies B[q % 3] and loads the weights of
     // k-step q + 2 into B[(q + 2) % 3]; the next chunk's patch is loaded in two goes and cut into the other buffer
