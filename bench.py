@@ -50,7 +50,7 @@ MFMA_DTYPE = {"f32": "f32",
               "f16x2": "f16 (2 scaled pieces per fp32 operand = 22 significand bits, 3 MFMAs per product, main and "
                        "2^-11-weighted cross terms in separate fp32 accumulators)"}
 DTYPE = {"f32": "f32", "bf16x3": "f32 via bf16x3 split (6 bf16 MFMAs per product, f32 accumulate)",
-         "f16x2": "f32 via f16x2 split (3 f16 MFMAs per product, f32 accumulate)"}
+         "f16x2": "f32 via f16x2 split (3 f16 MFMAs per product, f32 accumulate; the 14 large-channel conv launches of a closure as Winograd F(2,3) in that arithmetic)"}
 
 
 TRAFFIC_PROFILES = ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")
