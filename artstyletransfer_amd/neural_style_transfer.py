@@ -92,6 +92,109 @@ class LossBuilder:
         return losses[0], losses[1], losses[2], losses[3]
 
 
+class _DeviceJob:
+    """Everything one job owns on the GPU: the engine (targets, workspace), the optimiser (Adam moments / L-BFGS
+    history), the job's HIP stream, the side stream and the two pinned host buffers of the per-step yield.
+    `NeuralStyleTransfer.process` drives it through four calls - step (pool thread), snapshot, image, close - and is
+    otherwise plain asyncio, so the hand-over and tear-down ordering can be tested with a fake in its place
+    (`_make_job`, tests/test_host_api.py)."""
+
+    def __init__(self, device, optimizer_name, style_imgs, content_imgs, init_img, lr_start):
+        self.dev = dev = device
+        self.optimizer = None
+        self.engine = StyleEngine(load_weights(), dev)
+        h0, w0 = init_img.shape[:2]
+        # Every job runs on a HIP stream of its own: the jobs that share a GPU (`config.simultaneous_tasks_count`
+        # per GPU, as in the reference) then overlap on the device - one job's launch tails, host round trips and
+        # HBM-bound kernels run under the other's MFMA-bound ones - instead of queueing behind each other on the
+        # default stream.  The current stream is per THREAD and the jobs' coroutines share the event-loop thread, so
+        # it is set around synchronous sections only, never across an await.
+        self.job_stream = torch.cuda.Stream(device=dev)
+        self.job_stream.wait_stream(torch.cuda.current_stream(dev))     # the caller built the input images there
+        self.copy_stream = torch.cuda.Stream(device=dev)
+        try:
+            engine = self.engine
+
+            def prepared(img):      # numpy HWC (reference) or a device HWC tensor built by device_image
+                if isinstance(img, torch.Tensor):
+                    return engine.prepare_img(img.to(dev).contiguous())
+                return prepare_img(img, dev)
+
+            with torch.cuda.stream(self.job_stream):
+                engine.configure(len(content_imgs), h0, w0)
+                for lvl, (c_img, s_img) in enumerate(zip(content_imgs, style_imgs)):
+                    if tuple(c_img.shape[:2]) != engine.level_shape(lvl):
+                        raise ValueError(f"content level {lvl} is {tuple(c_img.shape[:2])}, expected {engine.level_shape(lvl)}")
+                    engine.set_targets(lvl, prepared(c_img), prepared(s_img))
+                self.x = prepared(init_img)
+                self.optimizer = PixelOptimizer(engine, optimizer_name, lr_start, LBFGS_MAX_EVAL)
+            # Per-step yield (reference :207-208): the image is un-prepared into its own device buffer, copied to
+            # pinned host memory on a side stream, and the NEXT optimiser step is started before that copy is
+            # awaited, so the 4*3*H*W-byte D2H hides under the next closures.
+            self.host = [torch.empty((h0, w0, 3), dtype=torch.float32, pin_memory=True) for _ in range(2)]
+        except BaseException:
+            self.close()
+            raise
+
+    def step(self, cw, sw, tvw):
+        """One optimizer.step(closure) (nst_opt_step).  Runs on a pool thread, whose current stream is its own."""
+        with torch.cuda.stream(self.job_stream):
+            return self.optimizer.step(self.x, cw, sw, tvw, want_losses=True)
+
+    def snapshot(self, k):
+        """Un-prepare the current image on the job's stream (ordered BEFORE the next step, which the caller starts
+        after this returns) and start its D2H into host buffer k on the side stream.  Returns a callable that blocks
+        until the copy has landed."""
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.job_stream):
+            snap = self.engine.unprepare_img(self.x)
+            ready = torch.cuda.Event()
+            ready.record()
+            with torch.cuda.stream(self.copy_stream):
+                self.copy_stream.wait_event(ready)
+                self.host[k].copy_(snap, non_blocking=True)
+                snap.record_stream(self.copy_stream)
+                done = torch.cuda.Event()
+                done.record()
+        return done.synchronize
+
+    def image(self, k):
+        return self.host[k].numpy().copy()
+
+    def close(self):
+        """The optimiser goes first (its curvature history alone is up to 200 x 12*H*W bytes), then the engine it was
+        created on.  The caller guarantees that no step is running (process() drains the worker thread first)."""
+        if self.optimizer is not None:
+            self.optimizer.close()
+            self.optimizer = None
+        self.job_stream.synchronize()
+        self.copy_stream.synchronize()
+        self.engine.close()
+
+
+def _make_job(device, optimizer_name, style_imgs, content_imgs, init_img, lr_start):
+    return _DeviceJob(device, optimizer_name, style_imgs, content_imgs, init_img, lr_start)
+
+
+async def _drain(step_future):
+    """Returns when the WORKER THREAD has left the optimiser step behind `step_future` (the asyncio future
+    run_in_executor returned).  Every await on that future goes through asyncio.shield, so cancelling the task never
+    cancels the future itself - a cancelled run_in_executor future says nothing about its thread, which would go on
+    inside nst_opt_step while the clean-up frees the optimiser and the engine under it.  A CancelledError that arrives
+    while waiting is kept and returned for the caller to re-raise after the clean-up."""
+    cancelled = None
+    while not step_future.done():
+        try:
+            await asyncio.shield(step_future)
+        except asyncio.CancelledError as e:
+            if not step_future.done():
+                cancelled = e                    # the task was cancelled (again); the thread is still in the step
+        except BaseException:
+            pass                                 # the step's own failure: the future is done
+    if not step_future.cancelled():
+        step_future.exception()                  # retrieved: an abandoned step must not warn at garbage collection
+    return cancelled
+
+
 class NeuralStyleTransfer:
     """The optimisation loop (reference :115-208)."""
 
@@ -109,88 +212,44 @@ class NeuralStyleTransfer:
             raise RuntimeError("Unknown optimizer")
         if self.__device.type != "cuda":
             raise RuntimeError("the HIP style-transfer engine needs a GPU; no CPU path exists")
-        dev = self.__device
-        h0, w0 = init_img.shape[:2]
-        engine = StyleEngine(load_weights(), dev)
-        # Every job runs on a HIP stream of its own: the jobs that share a GPU (`config.simultaneous_tasks_count`
-        # per GPU, as in the reference) then overlap on the device - one job's launch tails, host round trips and
-        # HBM-bound kernels run under the other's MFMA-bound ones - instead of queueing behind each other on the
-        # default stream.  The current stream is per THREAD and the jobs' coroutines share the event-loop thread, so
-        # it is set around synchronous sections only, never across an await.
-        job_stream = torch.cuda.Stream(device=dev)
-        job_stream.wait_stream(torch.cuda.current_stream(dev))     # the caller built the input images there
-        optimizer = None
-        try:
-            def prepared(img):      # numpy HWC (reference) or a device HWC tensor built by device_image
-                if isinstance(img, torch.Tensor):
-                    return engine.prepare_img(img.to(dev).contiguous())
-                return prepare_img(img, dev)
+        job = _make_job(self.__device, self.__optimizer_name, self.__style_imgs, content_imgs, init_img, lr_start)
+        cw, sw, tvw = float(content_weight), float(style_weight), float(tv_weight)
+        loop = asyncio.get_running_loop()
 
-            with torch.cuda.stream(job_stream):
-                engine.configure(len(content_imgs), h0, w0)
-                for lvl, (c_img, s_img) in enumerate(zip(content_imgs, self.__style_imgs)):
-                    if tuple(c_img.shape[:2]) != engine.level_shape(lvl):
-                        raise ValueError(f"content level {lvl} is {tuple(c_img.shape[:2])}, expected {engine.level_shape(lvl)}")
-                    engine.set_targets(lvl, prepared(c_img), prepared(s_img))
-                optimizing_img = prepared(init_img)
-                optimizer = PixelOptimizer(engine, self.__optimizer_name, lr_start, LBFGS_MAX_EVAL)
-            cw, sw, tvw = float(content_weight), float(style_weight), float(tv_weight)
-            step = 0
-
-            def one_step():
-                try:
-                    with torch.cuda.stream(job_stream):         # a pool thread: its current stream is its own
-                        return optimizer.step(optimizing_img, cw, sw, tvw, want_losses=True)
-                except Exception:
-                    traceback.print_exc()
-                    raise
-
-            loop = asyncio.get_running_loop()
-            # Per-step yield (reference :207-208): the image is un-prepared into its own device buffer, copied to
-            # pinned host memory on a side stream, and the NEXT optimiser step is started before that copy is
-            # awaited, so the 4*3*H*W-byte D2H hides under the next closures.
-            host = [torch.empty((h0, w0, 3), dtype=torch.float32, pin_memory=True) for _ in range(2)]
-            copy_stream = torch.cuda.Stream(device=dev)
-            k = 0
-            pending = loop.run_in_executor(None, one_step) if step < iters_num else None
+        def one_step():
             try:
-                while pending is not None:
-                    info, rows = await pending
-                    pending = None
-                    step = info.total_closures
-                    if VERBOSE:
-                        for r in rows:
-                            print(f"{self.__optimizer_name} | {init_img_name} | lr={info.lr:.4f} | total loss={r[-1]:.3e}")
-                    with torch.cuda.device(dev), torch.cuda.stream(job_stream):
-                        snap = engine.unprepare_img(optimizing_img)      # ordered before the next step on the stream
-                        ready = torch.cuda.Event()
-                        ready.record()
-                        if step < iters_num:
-                            pending = loop.run_in_executor(None, one_step)
-                        with torch.cuda.stream(copy_stream):
-                            copy_stream.wait_event(ready)
-                            host[k].copy_(snap, non_blocking=True)
-                            snap.record_stream(copy_stream)
-                            done = torch.cuda.Event()
-                            done.record()
-                    await loop.run_in_executor(None, done.synchronize)
-                    img = host[k].numpy().copy()
-                    k ^= 1
-                    yield img, step
-            finally:
-                if pending is not None:          # the consumer stopped early: let the running step finish
-                    try:
-                        await pending
-                    except BaseException:
-                        pass
+                return job.step(cw, sw, tvw)
+            except Exception:
+                traceback.print_exc()
+                raise
+
+        step, k = 0, 0
+        pending = loop.run_in_executor(None, one_step) if step < iters_num else None
+        cancelled = None
+        try:
+            while pending is not None:
+                info, rows = await asyncio.shield(pending)
+                pending = None
+                step = info.total_closures
+                if VERBOSE:
+                    for r in rows:
+                        print(f"{self.__optimizer_name} | {init_img_name} | lr={info.lr:.4f} | total loss={r[-1]:.3e}")
+                copied = job.snapshot(k)                 # ordered before the next step on the job's stream
+                if step < iters_num:
+                    pending = loop.run_in_executor(None, one_step)
+                await loop.run_in_executor(None, copied)
+                img = job.image(k)
+                k ^= 1
+                yield img, step
         finally:
             # Normal end, a consumer that stops early (aclose / GeneratorExit at the yield), a cancelled task or a
-            # failed step all come through here: the optimiser goes first (its curvature history alone is up to
-            # 200 x 12*H*W bytes), then the engine it was created on.
-            if optimizer is not None:
-                optimizer.close()
-            job_stream.synchronize()
-            engine.close()
+            # failed step all come through here.  First the worker thread itself is waited for (not the cancellable
+            # future around it), then the job's device objects go.
+            if pending is not None:
+                cancelled = await _drain(pending)
+            job.close()
+            if cancelled is not None:
+                raise cancelled
 
 
 async def resize(img, level):

@@ -14,7 +14,13 @@ NO hot-path arithmetic:
   (Conv2d 3x3 pad 1 / ReLU(inplace) / MaxPool2d 2x2) filled with the seeded synthetic
   weights (no pretrained file exists offline); ``transforms.Compose/ToTensor/Lambda/
   Normalize`` with torchvision's documented semantics for float32 HWC input.
-* ``cv2``: only so the module imports; no cv2 function is called by the paths used here.
+* ``cv2``: the four operators the reference's job set-up calls - ``resize(INTER_CUBIC)``, ``Sobel(ksize=5)``,
+  ``GaussianBlur``, ``getGaussianKernel`` - delegate to ``oracle/cv2_ref.py`` (the tap-by-tap restatement of OpenCV's
+  published definitions that ``tests/test_oracle_cv2.py`` pins against torch / scipy).  Everything AROUND those four
+  calls - the pyramid order and size rule, the granularity -> spot-grid rule, the envelope accumulation, the draw order
+  of ``np.random.permutation``, the Sobel / clip / blur / ``a = 5`` weight, the init-method branch
+  (neural_style_transfer.py:211-226, :249-362, :396-439) - is the reference's own Python, executed unmodified by the
+  ``jobsetup`` and ``config3`` fixtures.  The hot-path fixtures call no cv2 function.
 
 Fixtures hold data only (inputs, expected outputs); no reference source text.
 """
@@ -37,20 +43,41 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 REF = os.environ.get("NST_REFERENCE_DIR", "/root/reference")
 sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
 
 from oracle import cpu_ref  # noqa: E402  (synthetic input generators only)
 
 
 # ------------------------------------------------------------------ stand-ins
 def install_standins(weights):
+    from oracle import cv2_ref
+
     cv2 = types.ModuleType("cv2")
     cv2.INTER_CUBIC = 2
     cv2.CV_64F = 6
 
     def _absent(*a, **k):
-        raise RuntimeError("cv2 is absent offline; this path is not exercised by the fixtures")
+        raise RuntimeError("cv2 is absent offline; this function is not supplied by the stand-in")
 
-    for name in ("resize", "Sobel", "GaussianBlur", "getGaussianKernel", "imwrite", "cvtColor"):
+    def resize(src, dsize=None, interpolation=None, **kw):
+        assert interpolation == cv2.INTER_CUBIC and not kw, (interpolation, kw)
+        nw, nh = dsize
+        return cv2_ref.resize_cubic(np.asarray(src), int(nh), int(nw))
+
+    def Sobel(src, ddepth=None, dx=None, dy=None, ksize=3, **kw):
+        assert ddepth == cv2.CV_64F and ksize == 5 and not kw and (dx, dy) in ((1, 0), (0, 1))
+        return cv2_ref.sobel5(src, dx, dy)
+
+    def GaussianBlur(src, ksize=None, sigmaX=None, **kw):
+        assert ksize[0] == ksize[1] and sigmaX > 0 and not kw
+        return cv2_ref.gaussian_blur(src, int(ksize[0]), float(sigmaX))
+
+    def getGaussianKernel(n, sigma):
+        assert sigma > 0
+        return cv2_ref.get_gaussian_kernel(int(n), float(sigma)).reshape(-1, 1)        # cv2 returns an (n, 1) column
+
+    cv2.resize, cv2.Sobel, cv2.GaussianBlur, cv2.getGaussianKernel = resize, Sobel, GaussianBlur, getGaussianKernel
+    for name in ("imwrite", "cvtColor"):
         setattr(cv2, name, _absent)
     sys.modules["cv2"] = cv2
 
@@ -424,9 +451,147 @@ def fx_config3_prefix(ref_mu, ref_nn, ref_nst, weights):
              after_1=summarize(torch.from_numpy(imgs[0][0]), k=2048, seed=72))
 
 
+# ------------------------------------------------------------------ the reference's own job driver (f-1 / f-2)
+def _run_reference_job(ref_nst, content, style, cfg, seed, full_run=False):
+    """Runs the reference's own ``neural_style_transfer()`` (neural_style_transfer.py:229-372) with the cv2 stand-in
+    above.  ``NeuralStyleTransfer.process`` is wrapped to capture what the job driver hands to the hot path - the
+    content / style pyramids and the initial image - and, unless ``full_run``, to return at once.  ``np.random.seed(seed)``
+    is set immediately before the call (the reference draws its permutations from the global generator).  Returns
+    (captured dict, per-closure loss rows, [(percent, img), ...])."""
+    cap, rec, out = {}, [], []
+    orig_process = ref_nst.NeuralStyleTransfer.process
+    orig_init = ref_nst.NeuralStyleTransfer.__init__
+    orig_build = ref_nst.LossBuilder.build
+
+    def init(self, device, model_name, style_imgs, optimizer_name):
+        cap["style_imgs"] = [np.array(a, copy=True) for a in style_imgs]
+        cap["device"] = str(device)
+        orig_init(self, device, model_name, style_imgs, optimizer_name)
+
+    async def process(self, content_imgs, init_img, lr_start, iters_num, cw, sw, tvw, init_img_name):
+        cap["content_imgs"] = [np.array(a, copy=True) for a in content_imgs]
+        cap["init_img"] = np.array(init_img, copy=True)
+        cap["init_img_name"] = init_img_name
+        cap["lr_start"], cap["iters_num"], cap["weights"] = lr_start, iters_num, (cw, sw, tvw)
+        if full_run:
+            async for item in orig_process(self, content_imgs, init_img, lr_start, iters_num, cw, sw, tvw, init_img_name):
+                yield item
+
+    def build(self, x):
+        res = orig_build(self, x)
+        rec.append([float(v) for v in res])
+        return res
+
+    ref_nst.NeuralStyleTransfer.process = process
+    ref_nst.NeuralStyleTransfer.__init__ = init
+    ref_nst.LossBuilder.build = build
+    try:
+        pair = ref_nst.ContentStylePair(("content-name", content), ("style-name", style))
+
+        async def go():
+            np.random.seed(seed)
+            async for percent, img in ref_nst.neural_style_transfer(
+                    pair, cfg.content_weight, cfg.style_weight, cfg.tv_weight, cfg.optimizer, cfg.model, cfg.init_method,
+                    cfg.iters_num, cfg.levels_num, cfg.noise_factor, cfg.noise_levels, cfg.noise_levels_central_amplitude,
+                    cfg.noise_levels_peripheral_amplitude, cfg.noise_levels_dispersion):
+                out.append((float(percent), img.copy()))
+                if len(out) % 10 == 0:
+                    print(f"   ... {len(out)} optimiser steps, {len(rec)} level evaluations", file=sys.stderr, flush=True)
+
+        with contextlib.redirect_stdout(io.StringIO()):
+            asyncio.run(go())
+    finally:
+        ref_nst.NeuralStyleTransfer.process = orig_process
+        ref_nst.NeuralStyleTransfer.__init__ = orig_init
+        ref_nst.LossBuilder.build = orig_build
+        torch.autograd.set_detect_anomaly(False)
+    nlev = len(cap["content_imgs"])
+    rows = np.array(rec, dtype=np.float64).reshape(-1, nlev, 4) if rec and full_run else np.zeros((0, nlev, 4))
+    return cap, rows, out
+
+
+from jobsetup_cases import JOBSETUP_CASES  # noqa: E402  (numbers only: sizes, seeds, Config keyword arguments)
+
+
+def fx_jobsetup(ref_mu, ref_nn, ref_nst, weights):
+    """What the reference's job driver hands to the hot path (rows f-1 / f-2): level shapes, ordering, the content and
+    style pyramids and the structured-noise initial image, produced by the reference's own neural_style_transfer()."""
+    import config as ref_cfg
+    arrays = {"cases": np.array([c[0] for c in JOBSETUP_CASES])}
+    for tag, (ch, cw_, cs), (sh, sw_, ss), seed, kw in JOBSETUP_CASES:
+        content = cpu_ref.synthetic_image(ch, cw_, cs)
+        style = cpu_ref.synthetic_image(sh, sw_, ss)
+        cfg = ref_cfg.Config(iters_num=1, **kw)
+        cap, _, _ = _run_reference_job(ref_nst, content, style, cfg, seed)
+        n = len(cap["content_imgs"])
+        assert n == cfg.levels_num == len(cap["style_imgs"])
+        arrays[f"{tag}.content_shapes"] = np.array([a.shape for a in cap["content_imgs"]], dtype=np.int64)
+        arrays[f"{tag}.style_shapes"] = np.array([a.shape for a in cap["style_imgs"]], dtype=np.int64)
+        for l in range(n):
+            for k, v in summarize(torch.from_numpy(np.ascontiguousarray(cap["content_imgs"][l])), k=2048, seed=300 + l).items():
+                arrays[f"{tag}.content{l}.{k}"] = v
+            for k, v in summarize(torch.from_numpy(np.ascontiguousarray(cap["style_imgs"][l])), k=2048, seed=400 + l).items():
+                arrays[f"{tag}.style{l}.{k}"] = v
+        init = np.ascontiguousarray(cap["init_img"])
+        arrays[f"{tag}.init_dtype"] = np.array(str(init.dtype))
+        for k, v in summarize(torch.from_numpy(init), k=8192, seed=500).items():
+            arrays[f"{tag}.init.{k}"] = v
+        arrays[f"{tag}.init_name"] = np.array(cap["init_img_name"])
+        arrays[f"{tag}.lr_start"] = np.float64(cap["lr_start"])
+        print(f"   {tag}: levels {[tuple(a.shape) for a in cap['content_imgs']]}, init {init.shape} {init.dtype} "
+              f"'{cap['init_img_name']}'")
+    save("jobsetup", **arrays)
+
+
+def _config3_inputs():
+    return cpu_ref.synthetic_image(1024, 1536, seed=1), cpu_ref.synthetic_image(1024, 1536, seed=2)
+
+
+def _fx_config3(ref_nst, tag, optimizer, iters, max_eval=None):
+    """BASELINE config 3 through the reference's OWN job driver: neural_style_transfer() with Config() defaults except
+    levels_num = 3 (L=2: 1536x1024 + 768x512 + 384x256), init_method 'content+noise' with np.random.seed(0) immediately
+    before the call, synthetic 3:2 originals at the top level's size.  The start image is therefore the
+    reference's own structured-noise image (cv2 operators from oracle/cv2_ref).  Recorded: per-closure loss rows of all
+    three levels, sampled pixels of the start image and of the yielded images, the percent values."""
+    import config as ref_cfg
+    content, style = _config3_inputs()
+    cfg = ref_cfg.Config(levels_num=3, optimizer=optimizer, iters_num=iters)
+    orig_lbfgs = ref_nst.LBFGS
+    if max_eval is not None:
+        ref_nst.LBFGS = lambda params, **kw: orig_lbfgs(params, max_eval=max_eval, **kw)
+    try:
+        cap, rows, out = _run_reference_job(ref_nst, content, style, cfg, 0, full_run=True)
+    finally:
+        ref_nst.LBFGS = orig_lbfgs
+    init = np.ascontiguousarray(cap["init_img"])
+    imgs = [(img, p) for p, img in out]
+    arrays = dict(rows=rows, percent=np.array([p for p, _ in out], dtype=np.float64),
+                  moved=_moved(imgs, init), init=summarize(torch.from_numpy(init), k=8192, seed=500),
+                  final=summarize(torch.from_numpy(out[-1][1]), k=4096, seed=71),
+                  after_1=summarize(torch.from_numpy(out[0][1]), k=4096, seed=72))
+    for j in (1, 3, 9, 49):
+        if j < len(out) - 1:
+            arrays[f"after_{j + 1}"] = summarize(torch.from_numpy(out[j][1]), k=4096, seed=73 + j)
+    # closures consumed by every optimizer.step: percent = step / iters * 100 with step = the closure counter (:370)
+    arrays["steps"] = np.rint(arrays["percent"] / 100.0 * iters).astype(np.int64)
+    save(f"job_{tag}_1024x1536_L2", **arrays)
+
+
+def fx_config3_adam(ref_mu, ref_nn, ref_nst, weights):
+    """100 Adam iterations of the config-3 job (~20 min of CPU)."""
+    _fx_config3(ref_nst, "adam100", "adam", 100)
+
+
+def fx_config3_lbfgs(ref_mu, ref_nn, ref_nst, weights):
+    """24 closures of L-BFGS as the reference constructs it, and 40 closures of the legacy 25-evaluation line search."""
+    _fx_config3(ref_nst, "lbfgs24", "lbfgs", 24)
+    _fx_config3(ref_nst, "lbfgs_legacy40", "lbfgs", 40, max_eval=26)
+
+
 ALL = {f.__name__[3:]: f for f in (fx_kat, fx_bicubic, fx_vgg, fx_closure_small, fx_closure_odd, fx_closure_L0,
                                    fx_adam_small, fx_lbfgs_small, fx_adam_L0, fx_adam_config2geo,
-                                   fx_lbfgs_config2geo_legacy, fx_lbfgs_config2, fx_config3_prefix)}
+                                   fx_lbfgs_config2geo_legacy, fx_lbfgs_config2, fx_config3_prefix, fx_jobsetup,
+                                   fx_config3_adam, fx_config3_lbfgs)}
 
 
 def main():

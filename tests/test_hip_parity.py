@@ -787,6 +787,69 @@ def test_device_pyramid_and_noise_init_vs_oracle(eng):
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=1e-5)
 
 
+def _jobsetup_cases():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    from jobsetup_cases import JOBSETUP_CASES
+    return JOBSETUP_CASES
+
+
+@pytest.mark.parametrize("case", _jobsetup_cases(), ids=[c[0] for c in _jobsetup_cases()])
+def test_product_job_driver_vs_reference_fixture(vgg_weights, golden, case):
+    """The PRODUCT's own `neural_style_transfer()` job driver (device pyramid + structured-noise initial image) against
+    what the reference's own `neural_style_transfer()` handed to its hot path on the same (content, style, seed, Config):
+    tests/golden/jobsetup.npz (make_fixtures.py fx_jobsetup runs the reference's driver unmodified, its four cv2 operator
+    calls served by oracle/cv2_ref.py).  `NeuralStyleTransfer.process` is wrapped exactly as the fixture generator wraps the
+    reference's: level order and shapes, every pyramid level, the initial image, its name, lr_start."""
+    import asyncio
+    from test_oracle_jobsetup import job_inputs, summary_diff
+    from artstyletransfer_amd import neural_nets
+    import artstyletransfer_amd.neural_style_transfer as nst
+    neural_nets.set_weights(vgg_weights)
+    fx = golden("jobsetup")
+    tag, content, style, seed, cfg = job_inputs(case)
+    cap = {}
+    orig_init, orig_process = nst.NeuralStyleTransfer.__init__, nst.NeuralStyleTransfer.process
+
+    def init(self, device, model_name, style_imgs, optimizer_name):
+        cap["style"] = [t.cpu().numpy() for t in style_imgs]
+        orig_init(self, device, model_name, style_imgs, optimizer_name)
+
+    async def process(self, content_imgs, init_img, lr_start, iters_num, cw, sw, tvw, init_img_name):
+        cap["content"] = [t.cpu().numpy() for t in content_imgs]
+        cap["init"], cap["name"], cap["lr"] = init_img.cpu().numpy(), init_img_name, lr_start
+        return
+        yield                                                         # an async generator that yields nothing
+
+    nst.NeuralStyleTransfer.__init__, nst.NeuralStyleTransfer.process = init, process
+    try:
+        async def go():
+            np.random.seed(seed)
+            async for _ in nst.neural_style_transfer(
+                    nst.ContentStylePair(("content-name", content), ("style-name", style)), 1e3, 4e5, 1e2, "lbfgs", "vgg19",
+                    cfg["init_method"], 1, cfg["levels_num"], cfg["noise_factor"], cfg["noise_levels"],
+                    cfg["noise_levels_central_amplitude"], cfg["noise_levels_peripheral_amplitude"],
+                    cfg["noise_levels_dispersion"]):
+                pass
+        asyncio.run(go())
+    finally:
+        nst.NeuralStyleTransfer.__init__, nst.NeuralStyleTransfer.process = orig_init, orig_process
+    assert [list(a.shape) for a in cap["content"]] == fx[f"{tag}.content_shapes"].tolist()
+    assert [list(a.shape) for a in cap["style"]] == fx[f"{tag}.style_shapes"].tolist()
+    worst = 0.0
+    for l, (c, s) in enumerate(zip(cap["content"], cap["style"])):
+        for arr, key in ((c, f"{tag}.content{l}"), (s, f"{tag}.style{l}")):
+            d, sq = summary_diff(arr, fx, key)
+            worst = max(worst, d)
+            assert d <= _resize_atol(*arr.shape[:2]) and sq < 1e-5, (key, d, sq)
+    d, sq = summary_diff(cap["init"], fx, f"{tag}.init")
+    report(f"product job driver '{tag}': pyramid max |diff| vs the reference-made fixture {worst:.1e}; initial image "
+           f"{cap['init'].shape} max {d:.1e}, sum of squares rel {sq:.1e}")
+    assert d <= 2e-5 + _resize_atol(*cap["init"].shape[:2]) and sq < 1e-5, (tag, d, sq)
+    assert cap["name"] == str(fx[f"{tag}.init_name"]) and cap["lr"] == float(fx[f"{tag}.lr_start"])
+
+
 # ---------------------------------------------------------------- drop-in entry points, end to end
 def test_neural_style_transfer_generator_end_to_end(vgg_weights):
     """The reference's job API on the GPU: async generator yields (percent, HWC float32 image) per optimiser
