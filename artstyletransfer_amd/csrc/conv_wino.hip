@@ -32,6 +32,29 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// Diagnostic build only (-DNST_WINO_STAMPS, tools/micro/wino_probe.hip): wave 0 of every workgroup leaves the shader clock at the
+// phase boundaries in a buffer of its own that nothing else reads.  The shipped library is built without it.
+#ifdef NST_WINO_STAMPS
+__device__ unsigned long long g_wino_stamps[(1 << 14) * 8];
+#define WSTAMP(k)                                                                                      \
+    do {                                                                                               \
+        if (tid == 0 && blockIdx.x < (1 << 14)) g_wino_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define WSTAMP_REAL(k)                                                                                 \
+    do {                                                                                               \
+        if (tid == 0 && blockIdx.x < (1 << 14)) g_wino_stamps[blockIdx.x * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+#else
+#define WSTAMP(k)
+#define WSTAMP_REAL(k)
+#endif
+
+// timing-only experiment builds of the probe (WRONG results): bit 0 no weight loads in the K loop, 1 no patch loads, 2 no
+// transform / cut arithmetic, 3 no patch writes to LDS, 4 no A-fragment reads, 5 no barrier
+#ifndef NST_WINO_ABL
+#define NST_WINO_ABL 0
+#endif
+
 namespace {
 
 constexpr int W_TH = 8, W_TW = 16, W_PAIRS = 8, W_PH = W_TH + 2;
@@ -72,11 +95,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int xi = wave & 3, wn = wave >> 2;
     const int half = lane >> 5, l31 = lane & 31;
+    WSTAMP_REAL(6);
+    WSTAMP(0);
 
     // tile of this workgroup
     const int n_ct = b.Cout >> 7;
     const int t = xcd_order((int)blockIdx.x, (int)gridDim.x);
+#if NST_WINO_ABL & 512
+    // output-channel-tile major: a contiguous range of t (one XCD's share) stays on one ct as long as possible
+    const int n_sp = (int)gridDim.x / n_ct;
+    const int ct = t / n_sp, sp_all = t - ct * n_sp;
+#else
     const int sp_all = t / n_ct, ct = t - sp_all * n_ct;
+#endif
     int ii = 0;
     while (ii + 1 < b.n && sp_all >= b.img[ii].tile_end) ++ii;
     ii = __builtin_amdgcn_readfirstlane(ii);      // (provably wave-uniform: the image's pointers then live in scalar registers)
@@ -120,88 +151,136 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { accm[a][c][r] = 0.f; accx[a][c][r] = 0.f; }
 
-    // ---- patch staging: task u = (patch row, pair, channel quad): four pixels in, four transformed units out
-    struct Stage { f32x4 d[4]; unsigned code[UNPOOL ? 4 : 1]; };
+    // ---- patch staging.  Task (patch row, output pair p, channel quad): the pair's own two pixels E = (x0 + 2p), O = (x0 + 2p + 1)
+    // are loaded ONCE; the transform's outer columns d0 = O of pair p - 1 and d3 = E of pair p + 1 come from the neighbouring
+    // tasks' registers (ds_bpermute: a wave holds one patch row, 8 pairs x 8 quads), and the two halo columns x0 - 1, x0 + 16
+    // from one more load that only the end pairs' lanes take part in: 18 pixel columns fetched per row instead of 32.
+    // Lane -> pair: the 8-lane groups hold pairs 0, 4, 1, 5, 2, 6, 3, 7, so that the 16 lanes one ds_write_b64 pass serves
+    // write rows 4 pairs = 576 B = 16 banks apart: conflict-free (neighbouring pairs, 144 B apart, collide on 12 of 16 banks).
+    auto pair_of = [](int l) { const int g = (l >> 3) & 7; return (g >> 1) + 4 * (g & 1); };
+    auto lane_of = [](int pr, int sub) { return ((2 * (pr & 3) + ((pr >> 2) & 1)) * 8 + sub) * 4; };      // byte address for ds_bpermute
+    constexpr unsigned OOB = 0xFFFFFF00u;
+    struct Stage { f32x4 e, o, h; unsigned ce[UNPOOL ? 2 : 1], ch[1]; };       // UNPOOL: e = the pooled pixel both E and O come from
     auto task_load = [&](Stage& st, int u, int chunk) {
-        const int row = u >> 6, pair = (u >> 3) & 7, quad = u & 7;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gy = y0 - 1 + row, gx = x0 + 2 * pair - 1 + j;
-            bool ok = (u < W_PH * 64) & ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-            if (!UNPOOL) {
-                const unsigned voff = ok ? ((unsigned)(gy * W + gx) * (unsigned)Cin + (unsigned)quad * 4u) * 4u : 0xFFFFFF00u;
-                st.d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, chunk * 128, 0));
-            } else {
-                ok = ok & ((gy >> 1) < PH2) & ((gx >> 1) < PW2);          // the odd last row / column belongs to no window
-                const unsigned pp = (unsigned)((gy >> 1) * PW2 + (gx >> 1));
-                const unsigned voff = ok ? (pp * (unsigned)Cin + (unsigned)quad * 4u) * 4u : 0xFFFFFF00u;
-                const unsigned coff = ok ? ((pp * (unsigned)(Cin >> 5)) * 4u + (unsigned)((gy & 1) * 2 + (gx & 1))) * 4u : 0xFFFFFF00u;
-                st.d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, voff, chunk * 128, 0));
-                st.code[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_code, coff, chunk * 16, 0);
-            }
+        const int row = u >> 6, quad = u & 7, pair = pair_of(u);
+        const int gy = y0 - 1 + row, gx = x0 + 2 * pair;
+        const int hx = pair == 0 ? x0 - 1 : x0 + 16;                        // halo column of the end pairs
+        const bool hsel = (pair == 0) | (pair == 7);
+        if (!UNPOOL) {
+            const bool rowok = (unsigned)gy < (unsigned)H;
+            const unsigned base = ((unsigned)(gy * W + gx) * (unsigned)Cin + (unsigned)quad * 4u) * 4u;
+            const unsigned hoff = ((unsigned)(gy * W + hx) * (unsigned)Cin + (unsigned)quad * 4u) * 4u;
+            st.e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (rowok & (gx < W)) ? base : OOB, chunk * 128, 0));
+            st.o = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (rowok & (gx + 1 < W)) ? base + (unsigned)Cin * 4u : OOB, chunk * 128, 0));
+            st.h = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (rowok & hsel & ((unsigned)hx < (unsigned)W)) ? hoff : OOB, chunk * 128, 0));
+        } else {
+            // the odd last row / column belongs to no window
+            const bool rowok = ((unsigned)gy < (unsigned)H) & ((gy >> 1) < PH2);
+            const int pxl = (x0 >> 1) + pair, phx = hx >> 1;                 // pooled columns (x0 is a multiple of 16)
+            const bool ok = rowok & (pxl < PW2), hok = rowok & hsel & (hx >= 0) & (phx < PW2);
+            const unsigned pp = (unsigned)((gy >> 1) * PW2 + pxl), hp = (unsigned)((gy >> 1) * PW2 + phx);
+            const unsigned pos = (unsigned)(gy & 1) * 2u;                    // window position of E; O is the next one
+            st.e = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, ok ? (pp * (unsigned)Cin + (unsigned)quad * 4u) * 4u : OOB, chunk * 128, 0));
+            const u32x2 c2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_code, ok ? ((pp * (unsigned)(Cin >> 5)) * 4u + pos) * 4u : OOB, chunk * 16, 0));
+            st.ce[0] = c2[0];
+            st.ce[UNPOOL ? 1 : 0] = c2[1];
+            st.h = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, hok ? (hp * (unsigned)Cin + (unsigned)quad * 4u) * 4u : OOB, chunk * 128, 0));
+            st.ch[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_code, hok ? ((hp * (unsigned)(Cin >> 5)) * 4u + pos + (unsigned)(hx & 1)) * 4u : OOB, chunk * 16, 0);
         }
     };
     auto task_store = [&](const Stage& st, int u, unsigned char* buf) {
-        if (u >= W_PH * 64) return;
-        const int row = u >> 6, pair = (u >> 3) & 7, quad = u & 7;
-        f32x4 d[4] = {st.d[0], st.d[1], st.d[2], st.d[3]};
+        const int row = u >> 6, quad = u & 7, pair = pair_of(u);
+        f32x4 E = st.e, O = st.o, Hh = st.h;
         if (UNPOOL) {
             // an element of the pooled gradient goes to the window position that held the (first, positive) maximum
+            const unsigned be = st.ce[0] >> (quad * 4), bo = st.ce[UNPOOL ? 1 : 0] >> (quad * 4), bh = st.ch[0] >> (quad * 4);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const unsigned bits = st.code[UNPOOL ? j : 0] >> (quad * 4);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) d[j][k] = ((bits >> k) & 1u) ? d[j][k] : 0.f;
+            for (int k = 0; k < 4; ++k) {
+                O[k] = ((bo >> k) & 1u) ? st.e[k] : 0.f;
+                E[k] = ((be >> k) & 1u) ? st.e[k] : 0.f;
+                Hh[k] = ((bh >> k) & 1u) ? st.h[k] : 0.f;
             }
         }
-        const f32x4 tt[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
+        const int src0 = lane_of(pair - 1, quad), src3 = lane_of(pair + 1, quad);
+        f32x4 d0, d3;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            d0[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src0, __float_as_int(O[k])));
+            d3[k] = __int_as_float(__builtin_amdgcn_ds_bpermute(src3, __float_as_int(E[k])));
+        }
+        if (pair == 0) d0 = Hh;
+        if (pair == 7) d3 = Hh;
+        const f32x4 tt[4] = {d0 - O, E + O, O - E, E - d3};
         unsigned char* base = buf + row * W_PROWB + pair * W_ROWB + quad * 8;
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             u32x2 hi, lo;
+#if NST_WINO_ABL & 4
+            hi = u32x2{__float_as_uint(tt[0][x]), __float_as_uint(E[x])};
+            lo = u32x2{__float_as_uint(O[x]), __float_as_uint(d3[x])};
+#else
             cut2x4(tt[x], sa, hi, lo);
+#endif
             *reinterpret_cast<u32x2*>(base + x * W_PAIRS * W_ROWB) = hi;
             *reinterpret_cast<u32x2*>(base + x * W_PAIRS * W_ROWB + 64) = lo;
         }
     };
 
-    // The last two patch rows (8 pairs x 32 channels each = 512 one-channel tasks) are every thread's second task: four
-    // 4-byte loads, one channel through the same transform and cut.  (As 128 more four-channel tasks they kept 16 staging
-    // registers of EVERY thread busy for two waves' sake.)
-    struct Stage1 { float d[4]; unsigned code[UNPOOL ? 4 : 1]; };
+    // The last two patch rows (8 pairs x 32 channels each = 512 one-channel tasks) are every thread's second task: 4-byte
+    // loads, one channel through the same exchange, transform and cut.  (As 128 more four-channel tasks they kept 12 staging
+    // registers of EVERY thread busy for two waves' sake.)  Wave w: patch row 8 + (w >> 2), channels 8 (w & 3) .. + 8; its
+    // lanes: the same pair order as above, channel = lane & 7.
+    struct Stage1 { float e, o, h; unsigned ce[UNPOOL ? 2 : 1], ch[1]; };
     auto row_load = [&](Stage1& st, int u, int chunk) {
-        const int row = 8 + (u >> 8), pair = (u >> 5) & 7, ch = u & 31;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int gy = y0 - 1 + row, gx = x0 + 2 * pair - 1 + j;
-            bool ok = ((unsigned)gy < (unsigned)H) & ((unsigned)gx < (unsigned)W);
-            if (!UNPOOL) {
-                const unsigned voff = ok ? ((unsigned)(gy * W + gx) * (unsigned)Cin + (unsigned)ch) * 4u : 0xFFFFFF00u;
-                st.d[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, chunk * 128, 0));
-            } else {
-                ok = ok & ((gy >> 1) < PH2) & ((gx >> 1) < PW2);
-                const unsigned pp = (unsigned)((gy >> 1) * PW2 + (gx >> 1));
-                const unsigned voff = ok ? (pp * (unsigned)Cin + (unsigned)ch) * 4u : 0xFFFFFF00u;
-                const unsigned coff = ok ? ((pp * (unsigned)(Cin >> 5)) * 4u + (unsigned)((gy & 1) * 2 + (gx & 1))) * 4u : 0xFFFFFF00u;
-                st.d[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, voff, chunk * 128, 0));
-                st.code[j] = __builtin_amdgcn_raw_buffer_load_b32(rs_code, coff, chunk * 16, 0);
-            }
+        const int wv = u >> 6, row = 8 + (wv >> 2), ch = (wv & 3) * 8 + (u & 7), pair = pair_of(u);
+        const int gy = y0 - 1 + row, gx = x0 + 2 * pair;
+        const int hx = pair == 0 ? x0 - 1 : x0 + 16;
+        const bool hsel = (pair == 0) | (pair == 7);
+        if (!UNPOOL) {
+            const bool rowok = (unsigned)gy < (unsigned)H;
+            const unsigned base = ((unsigned)(gy * W + gx) * (unsigned)Cin + (unsigned)ch) * 4u;
+            const unsigned hoff = ((unsigned)(gy * W + hx) * (unsigned)Cin + (unsigned)ch) * 4u;
+            st.e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, (rowok & (gx < W)) ? base : OOB, chunk * 128, 0));
+            st.o = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, (rowok & (gx + 1 < W)) ? base + (unsigned)Cin * 4u : OOB, chunk * 128, 0));
+            st.h = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, (rowok & hsel & ((unsigned)hx < (unsigned)W)) ? hoff : OOB, chunk * 128, 0));
+        } else {
+            const bool rowok = ((unsigned)gy < (unsigned)H) & ((gy >> 1) < PH2);
+            const int pxl = (x0 >> 1) + pair, phx = hx >> 1;
+            const bool ok = rowok & (pxl < PW2), hok = rowok & hsel & (hx >= 0) & (phx < PW2);
+            const unsigned pp = (unsigned)((gy >> 1) * PW2 + pxl), hp = (unsigned)((gy >> 1) * PW2 + phx);
+            const unsigned pos = (unsigned)(gy & 1) * 2u;
+            st.e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, ok ? (pp * (unsigned)Cin + (unsigned)ch) * 4u : OOB, chunk * 128, 0));
+            const u32x2 c2 = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_code, ok ? ((pp * (unsigned)(Cin >> 5)) * 4u + pos) * 4u : OOB, chunk * 16, 0));
+            st.ce[0] = c2[0];
+            st.ce[UNPOOL ? 1 : 0] = c2[1];
+            st.h = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_in, hok ? (hp * (unsigned)Cin + (unsigned)ch) * 4u : OOB, chunk * 128, 0));
+            st.ch[0] = __builtin_amdgcn_raw_buffer_load_b32(rs_code, hok ? ((hp * (unsigned)(Cin >> 5)) * 4u + pos + (unsigned)(hx & 1)) * 4u : OOB, chunk * 16, 0);
         }
     };
     auto row_store = [&](const Stage1& st, int u, unsigned char* buf) {
-        const int row = 8 + (u >> 8), pair = (u >> 5) & 7, ch = u & 31;
-        float d[4] = {st.d[0], st.d[1], st.d[2], st.d[3]};
+        const int wv = u >> 6, row = 8 + (wv >> 2), ch = (wv & 3) * 8 + (u & 7), pair = pair_of(u);
+        float E = st.e, O = st.o, Hh = st.h;
         if (UNPOOL) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) d[j] = ((st.code[UNPOOL ? j : 0] >> ch) & 1u) ? d[j] : 0.f;
+            O = ((st.ce[UNPOOL ? 1 : 0] >> ch) & 1u) ? st.e : 0.f;
+            E = ((st.ce[0] >> ch) & 1u) ? st.e : 0.f;
+            Hh = ((st.ch[0] >> ch) & 1u) ? st.h : 0.f;
         }
-        const float tt[4] = {d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]};
+        float d0 = __int_as_float(__builtin_amdgcn_ds_bpermute(lane_of(pair - 1, u & 7), __float_as_int(O)));
+        float d3 = __int_as_float(__builtin_amdgcn_ds_bpermute(lane_of(pair + 1, u & 7), __float_as_int(E)));
+        if (pair == 0) d0 = Hh;
+        if (pair == 7) d3 = Hh;
+        const float tt[4] = {d0 - O, E + O, O - E, E - d3};
         unsigned char* base = buf + row * W_PROWB + pair * W_ROWB + ch * 2;
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
+#if NST_WINO_ABL & 4
+            const _Float16 hi = __builtin_bit_cast(_Float16, (unsigned short)__float_as_uint(tt[x]));
+            const _Float16 lo = __builtin_bit_cast(_Float16, (unsigned short)(__float_as_uint(tt[x]) >> 16));
+#else
             const float v = tt[x] * sa;
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)((v - (float)hi) * LO_UP);
+#endif
             *reinterpret_cast<_Float16*>(base + x * W_PAIRS * W_ROWB) = hi;
             *reinterpret_cast<_Float16*>(base + x * W_PAIRS * W_ROWB + 64) = lo;
         }
@@ -229,8 +308,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
-                f.v[nt][s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16 + (nt * 2 + s) * 64 * 16, soff, 0));
+            for (int s = 0; s < 2; ++s) {
+#if NST_WINO_ABL & 64
+                if (s == 1) { f.v[nt][1] = f.v[nt][0]; continue; }      // half the weight bytes
+#endif
+                f.v[nt][s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16 + (nt * 2 + s) * 64 * 16, soff, (NST_WINO_ABL & 256) ? 2 : 0));
+            }
     };
     auto multiply = [&](const AF& a, const BF& w) {
 #pragma unroll
@@ -257,6 +340,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
         row_store(d1, tid, smem);
     }
     __syncthreads();
+    WSTAMP(1);
     read_a(A[0], smem, 0, 0);
     // (as in conv_h2.hip: the later-dispatched half of the workgroup loses issue arbitration to the older half at the start of
     // every stage; one s_setprio for that half, wave-uniform condition)
@@ -275,23 +359,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             // weights two k-steps ahead
-            {
-                const int q2 = q + 2;
+            if (!(NST_WINO_ABL & 1)) {
+                const int q2 = q + ((NST_WINO_ABL & 128) ? 1 : 2);
                 if (q2 < 6) load_b(B[q2 % 3], c, q2 >> 1, q2 & 1);
                 else load_b(B[q2 % 3], cn, (q2 - 6) >> 1, (q2 - 6) & 1);
             }
-            if (q == 0) task_load(d, to, cn);
-            if (q == 1) row_load(d1, to, cn);
+            if (!(NST_WINO_ABL & 2)) {
+                if (q == 0) task_load(d, to, cn);
+                if (q == 1) row_load(d1, to, cn);
+            }
             // next k-step's A fragments
-            if (q + 1 < 6) read_a(A[(q + 1) & 1], cur, (q + 1) >> 1, (q + 1) & 1);
+            if (!(NST_WINO_ABL & 16) && q + 1 < 6) read_a(A[(q + 1) & 1], cur, (q + 1) >> 1, (q + 1) & 1);
             multiply(A[q & 1], B[q % 3]);
-            if (q == 4) task_store(d, to, nxt);
-            if (q == 5) row_store(d1, to, nxt);
+            if (!(NST_WINO_ABL & 8)) {
+                if (q == 4) task_store(d, to, nxt);
+                if (q == 5) row_store(d1, to, nxt);
+            }
         }
-        __syncthreads();
-        if (c + 1 < nch) read_a(A[0], nxt, 0, 0);
+        if (!(NST_WINO_ABL & 32)) __syncthreads();
+        if (!(NST_WINO_ABL & 16) && c + 1 < nch) read_a(A[0], nxt, 0, 0);
     }
 
+    WSTAMP(2);
     // ---- epilogue: the four xi accumulators of every pair meet in LDS, one output-channel half at a time.  A thread then
     // owns a 2x2 pixel window (image rows 2 yp, 2 yp + 1 of the tile, output pair p) x 4 channels: output transform, bias /
     // addend, ReLU / ReLU mask, 16-byte stores, and - where a pooling layer follows - the window's maximum and arg-max code.
@@ -313,6 +402,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     if (im.bits_out) WB[tid] = 0u;
     if (im.pcode_out) PC[tid] = 0u;
     __syncthreads();
+    WSTAMP(3);
     for (int pass = 0; pass < 2; ++pass) {      // the two 64-channel halves of the tile, one after the other per thread
         const int co = n0 + pass * 64 + cq * 4;
         const f32x4 bv = b.bias ? *reinterpret_cast<const f32x4*>(b.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
@@ -405,6 +495,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
         for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
         if (lane == 0) atomicMax(im.amax_out + ((blockIdx.x * 8 + wave) & (NST_AMAX_SLOTS - 1)), __float_as_uint(amax));
     }
+    WSTAMP(4);
+#ifdef NST_WINO_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (diagnostic build: the stores have left the wave)
+#endif
+    WSTAMP(5);
+    WSTAMP_REAL(7);
 }
 
 hipError_t conv_wino_init_device() {

@@ -470,11 +470,11 @@ class PixelOptimizer:
         self._pack = torch.zeros(n + self.row, dtype=torch.float32, device=e.device)
         self._g = self._pack[:n].view(1, 3, H, W)
         self._l = self._pack[n:]
-        # lower levels: level l >= 1 on rank l % world; level 0 is nobody's in the level mask (its stripes are added here)
+        # lower levels: dealt largest first onto the least-loaded rank (every rank carries an equal stripe of level 0);
+        # level 0 is nobody's in the level mask (its stripes are added here)
         mask = 0
-        for l in range(1, e.levels):
-            if l % world == rank:
-                mask |= 1 << l
+        for l in sharding.deal_levels(range(1, e.levels), world)[rank]:
+            mask |= 1 << l
 
         def hook(_user):
             x, (cw, sw, tvw) = self._x, self._w

@@ -330,6 +330,27 @@ def side_job(args, optimizer, max_eval, closures, warm, **engine_options):
     return out, eng, opt, job
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` started plainly (no launcher, no WORLD_SIZE): run N ranks of this script under
+    torch.distributed.run as a child process and return its exit code.  Called before anything touches the GPU - a
+    process that has initialised HIP must never exec or fork GPU work."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd).returncode
+
+
+def ranks_present(dist, device) -> int:
+    """How many ranks take part in a collective: every rank contributes 1 to an all-reduce."""
+    one = torch.ones(1, dtype=torch.float32, device=device if device is not None else "cpu")
+    dist.all_reduce(one)
+    return int(round(float(one.item())))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -352,6 +373,9 @@ def main():
                     help="mode 'levels': the per-closure collective behind the C ABI (nst_comm_*: one ncclAllReduce of the "
                          "packed gradient + loss row) or through torch.distributed (needed for gloo rehearsals)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal on a 1-GPU box: every rank uses cuda:0")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="rehearsal of the launch path (works without a GPU): start the ranks, count them with one "
+                         "collective, print {ranks_seen, n_gpus} and leave before any device call")
     ap.add_argument("--jobs-per-gpu", type=int, default=1,
                     help="mode 'jobs' only: that many independent jobs per GPU, each on its own HIP stream and host "
                          "thread (the scheduler's simultaneous_tasks_count; 2 gives ~1.09x the aggregate rate). The "
@@ -362,11 +386,31 @@ def main():
                          "closure (BASELINE config 4, strong scaling, capped at 1.33x by the 75/19/5/1 % split)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started plainly: launch the N ranks ourselves, as CHILD processes of a parent that has not touched the GPU
+        # (nothing above initialises HIP), and leave with the launcher's exit code.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU, e.g. python -m "
+                         f"torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py "
+                         f"--gpus {args.gpus} ... (or run bench.py --gpus {args.gpus} without WORLD_SIZE: it launches them)")
+    if args.rendezvous_only:
+        # rehearsal of the launch path on a box without GPUs: rendezvous, count the ranks, leave before any device call
+        import torch.distributed as dist
+        dist.init_process_group(args.dist_backend if world > 1 else "gloo")
+        seen = ranks_present(dist, None)
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world, "ranks_seen": seen,
+                              "backend": dist.get_backend()}), flush=True)
+        dist.destroy_process_group()
+        if seen != args.gpus:
+            raise SystemExit(f"{seen} ranks answered, --gpus {args.gpus}")
+        return
+    if not args.share_gpu and torch.cuda.device_count() < args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but this node shows {torch.cuda.device_count()} GPU(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
     if args.share_gpu:
@@ -379,6 +423,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(args.dist_backend)
+        seen = ranks_present(dist, torch.device("cuda", local_rank) if args.dist_backend == "nccl" else None)
+        if seen != args.gpus:
+            raise SystemExit(f"{seen} ranks answered the first collective, --gpus {args.gpus}")
 
     from artstyletransfer_amd.engine import Communicator, PixelOptimizer
     sharded = world > 1 and args.mode in ("levels", "stripes")
@@ -507,7 +554,7 @@ def main():
             r_, w_, calls, nbytes = comm.info()
             out["comm"] = {"ranks_seen": w_, "allreduce_calls": calls, "bytes_per_call": nbytes / max(calls, 1)}
         elif dist is not None:
-            out["comm"] = {"ranks_seen": dist.get_world_size(), "backend": args.dist_backend}
+            out["comm"] = {"ranks_seen": seen, "backend": args.dist_backend}
         if not args.no_kernel_timing:
             ms, n, fl = eng.timing_totals(0)
             cms, cn, _ = eng.timing_totals(-1)

@@ -240,3 +240,157 @@ def closure_vs_oracle_under_equal_decisions(eng, xt, tg, weights, what, terms=TE
 def pytest_approx(value, rel):
     import pytest
     return pytest.approx(value, rel=rel)
+
+
+# ---- the shipped L-BFGS against a run of the reference, its first two steps taken apart ---------------------------------
+def totals(rows):
+    return np.asarray(rows)[:, :, 0].sum(axis=1)
+
+
+def lbfgs_run(e, x, closures, max_eval=1, nlev=3):
+    from artstyletransfer_amd.engine import PixelOptimizer
+    opt = PixelOptimizer(e, "lbfgs", 10.0, max_eval)
+    rows, steps, moved, xs = [], [], [], [x.clone()]
+    total = 0
+    while total < closures:
+        info, r = opt.step(x, CW, SW, TVW)
+        total = info.total_closures
+        steps.append(total)
+        moved.append(bool(info.accepted))
+        rows.extend(list(r[:, :-1].reshape(-1, nlev, 4)))
+        xs.append(x.clone())
+    opt.close()
+    return np.array(rows), steps, moved, xs
+
+
+def _fp64_direction(g1, y, s):
+    """torch:optim/lbfgs.py:396-442 with ONE curvature pair, in double."""
+    g1, y, s = g1.double(), y.double(), s.double()
+    ys = float(y.dot(s))
+    q = -g1
+    al = float(s.dot(q)) / ys
+    q = q - al * y
+    r = q * (ys / float(y.dot(y)))
+    be = float(y.dot(r)) / ys
+    return r + (al - be) * s, ys
+
+
+def lbfgs_vs_reference_taken_apart(eng, vgg_weights, c_lv, s_lv, x_init, fx, closures, what):
+    """The shipped L-BFGS (max_eval 1) on a three-level job against a run of the reference (fixture `fx`: rows, steps, moved,
+    after_1): identical closure counts and accept / reject sequence, and the first two steps taken apart - see the numbered
+    blocks.  x_init: the prepared (1,3,H,W) start image (CPU tensor)."""
+    from artstyletransfer_amd.engine import StyleEngine
+    NLEV = len(c_lv)
+    H0, W0 = x_init.shape[2], x_init.shape[3]
+    setup(eng, c_lv, s_lv)
+    rows, steps, moved, xs = lbfgs_run(eng, dev(x_init), closures, nlev=NLEV)
+    assert steps == list(fx["steps"])                      # closures per optimizer.step
+    assert moved == list(fx["moved"])                      # accept / reject sequence
+    tot, ref = totals(rows), totals(fx["rows"])
+    err = np.abs(tot - ref) / ref
+    acc = [i for i, m in enumerate(moved) if m]
+    report(f"{what}: accepted steps {acc} of {len(moved)} "
+           f"(reference {[i for i, m in enumerate(fx['moved']) if m]}); total-loss rel err per closure " + np.array2string(err, precision=1))
+    # closures 0-2: x0, the first trial point (t = min(1, 1/|g|_1) lr: a tiny step) and its re-evaluation
+    check_rows(rows[:3], fx["rows"][:3], 2e-5)
+    final_err = abs(tot[-2] - ref[-2]) / ref[-2] if not moved[-1] else err[-1]
+    assert moved[0], "the first step (a 1/|g|_1-long step down the gradient) is accepted in the reference's run"
+
+    # ---- (1) teacher-forced: the oracle AT the device's own iterates (after step 1, after step 2), under the device's
+    # decisions: losses 1e-5, the whole gradient 2e-5 - the closure is right at the points the landing depends on
+    tg = [cpu_ref.LevelTargets(cpu_ref.prepare_img(c), cpu_ref.prepare_img(s), vgg_weights) for c, s in zip(c_lv, s_lv)]
+    grads, decs = [], []
+    lr2 = 10.0 * 0.999 ** 2                                # the group's lr read before step 2's first closure (two decays so far)
+    for k in (0, 1, 2):
+        if k == 2 and not moved[1]:
+            # step 2 was rejected: the trial point it evaluated is rebuilt from the device's own direction
+            s0, y0 = (xs[1] - xs[0]).reshape(-1), grads[1] - grads[0]
+            ys0 = float(y0.double().dot(s0.double()))
+            xs[2] = xs[1] + lr2 * eng.lbfgs_direction(grads[1], [y0], [s0], [1.0 / ys0], ys0 / float(y0.double().dot(y0.double())), 0).view_as(xs[1])
+        g, l = eng.closure(xs[k], CW, SW, TVW)
+        dec = device_decisions(eng, xs[k])
+        grads.append(g.reshape(-1).clone())
+        decs.append(dec)
+        if k == 0:
+            continue
+        lo, go, ro = cpu_ref.closure_eval(xs[k].cpu(), tg, vgg_weights, CW, SW, TVW, decisions=dec)
+        e_l = abs(float(l[-1].cpu()) - float(lo)) / float(lo)
+        e_g = rel_l2(g.cpu().numpy(), go.numpy())
+        report(f"{what}, teacher-forced at the device's iterate after step {k}: loss rel {e_l:.1e}, gradient rel-L2 under equal decisions {e_g:.1e}")
+        assert e_l < 1e-5 and e_g < 2e-5
+        check_rows(l[:-1].cpu().numpy().reshape(NLEV, 4), np.array(ro), 2e-5)
+
+    # ---- (2) the step-2 direction from the DEVICE's own (g0, g1, s) against an fp64 recursion, and the iterate it gives
+    s1 = (xs[1] - xs[0]).reshape(-1)
+    y1 = grads[1] - grads[0]
+    d64, ys = _fp64_direction(grads[1].cpu(), y1.cpu(), s1.cpu())
+    hd = ys / float(y1.double().dot(y1.double()))
+    cond = float(grads[1].double().norm() / y1.double().norm())
+    d_dev = eng.lbfgs_direction(grads[1], [y1], [s1], [1.0 / ys], hd, 0)
+    e_d = rel_l2(d_dev.cpu().numpy(), d64.numpy())
+    report(f"{what}, step-2 direction (nst_lbfgs_direction on the device's g0, g1, s) vs fp64: rel-L2 {e_d:.1e}; |g1| / |g1 - g0| = {cond:.1e} "
+           f"(what a relative error of the gradient is multiplied by in y = g1 - g0), y.s = {ys:.3e}, H_diag = {hd:.3e}")
+    assert e_d < 2e-5
+    if len(moved) > 1 and moved[1]:
+        e_x = rel_l2((xs[2].reshape(-1).double().cpu() - xs[1].reshape(-1).double().cpu()).numpy(), (lr2 * d64).numpy())
+        report(f"{what}, the device's step 2 (x2 - x1) vs lr * the fp64 direction from its own gradients: rel-L2 {e_x:.1e}")
+        assert e_x < 1e-4
+
+    # ---- (3) the ORACLE's optimiser (torch's L-BFGS restated) on the oracle's closure evaluated under the device's
+    # decisions at the corresponding point (closure 0: x0; closures 1, 2: the iterate after step 1; closure 3: after step 2)
+    st = cpu_ref.LbfgsState(max_eval=1)
+    xo = x_init.reshape(-1).clone()
+    calls, orc = [], []
+    point = {0: 0, 1: 1, 2: 1, 3: 2}
+
+    def closure(xf):
+        k = len(calls)
+        loss, g, r = cpu_ref.closure_eval(xf.view(1, 3, H0, W0), tg, vgg_weights, CW, SW, TVW, decisions=decs[point[k]])
+        calls.append(float(loss))
+        orc.append(np.array(r))
+        return float(loss), g.reshape(-1)
+
+    lr = 10.0
+    for _ in range(2):
+        cpu_ref.lbfgs_step(st, xo, lr, closure)
+        lr *= 0.999 ** 2
+    o_tot = np.array(calls)
+    e_land = np.abs(o_tot - tot[:4]) / tot[:4]
+    e_ref = np.abs(o_tot - ref[:4]) / ref[:4]
+    e_x2 = rel_l2(xo.numpy(), xs[2 if moved[1] else 1].reshape(-1).cpu().numpy())       # (a rejected step 2 leaves x1)
+    report(f"{what}, the oracle's optimiser under the DEVICE's decisions, closures 0-3: rel diff to the device " + np.array2string(e_land, precision=1)
+           + ", to the reference's run " + np.array2string(e_ref, precision=1) + f"; the device's own closures vs the reference " + np.array2string(err[:4], precision=1)
+           + f"; iterate after step 2 oracle vs device rel-L2 {e_x2:.1e}")
+    assert e_land[:3].max() < 2e-5
+    # ---- (4) every convolution direct (nst_options.h2_winograd = 0): the Winograd default does not move the landing
+    other = StyleEngine(vgg_weights, 0, h2_winograd=False)
+    try:
+        setup(other, c_lv, s_lv)
+        r2, st2, mv2, _ = lbfgs_run(other, dev(x_init), 4, nlev=NLEV)
+    finally:
+        other.close()
+    t2 = totals(r2)
+    e_dir = np.abs(t2[:4] - tot[:4]) / tot[:4]
+    report(f"{what}, all-direct convolutions vs the default (Winograd launches), closures 0-3: " + np.array2string(e_dir, precision=1)
+           + f"; vs the reference " + np.array2string(np.abs(t2[:4] - ref[:4]) / ref[:4], precision=1))
+    assert mv2 == moved[:2] and e_dir[:3].max() < 2e-5
+    # The landing of step 2: with the closure right at every visited point (1), the direction right given the gradients (2),
+    # what remains is the map (g0, g1) -> x2 itself: y = g1 - g0 is |g1| / |y| times smaller than the gradients, so a
+    # relative gradient difference e becomes ~e |g1| / |y| in H_diag = y.s / y.y and in the step.  Bounds: the oracle under
+    # the device's decisions must land where the device lands far closer than the device is to the reference's run (the
+    # decisions, not the products, carry the difference) ...
+    LAND = 3e-2
+    assert err[3] < LAND and e_dir[3] < LAND and e_land[3] < LAND
+    # ... and the run ends at the reference's loss level
+    report(f"{what}: loss at the last accepted point, device {tot[-2] if not moved[-1] else tot[-1]:.6e} vs reference "
+           f"{ref[-2] if not moved[-1] else ref[-1]:.6e} (rel {final_err:.2e})")
+    assert final_err < (LAND if any(moved[1:]) else 1e-3)      # no amplified step in the run: SURVEY 8(c)'s 1e-3
+    # rejected steps re-evaluate the kept image: bitwise the same row; their trial points are far up the loss surface
+    for i in range(1, len(steps)):
+        if not moved[i - 1]:
+            first = steps[i - 1]                            # index of step i's first closure
+            prev_first = steps[i - 2] if i >= 2 else 0
+            assert np.array_equal(rows[first], rows[prev_first]), i
+    check_summary(eng.unprepare_img(xs[1]).cpu(), fx, "after_1", atol=1e-4)
+
+

@@ -437,6 +437,17 @@ def test_options_default_to_the_environment(vgg_weights, monkeypatch):
         b.close()
 
 
+def _geometry_terms(geo, opts):
+    """Which loss terms a schedule is compared on, per term = one oracle forward + backward each.  The DEFAULT path
+    (batched levels + Winograd launches) is held on the weighted sum AND on every term alone on the two geometries that
+    reach the Winograd launches with edge tiles on all three levels and with a foreign-size style; on the sum elsewhere.
+    The other schedules: sum + TV (their TV signs are taken per schedule)."""
+    default = opts == dict(conv_mode="f16x2", batched=True, h2_band_rows=0)
+    if default:
+        return TERMS if geo in ((103, 151, 3, 136, 329), (336, 77, 3, 104, 271)) else (TERMS[0],)
+    return (TERMS[0], TERMS[3])
+
+
 @pytest.mark.parametrize("geo", [(63, 133, 1, 227, 293), (356, 151, 3, 356, 151), (103, 151, 3, 136, 329),
                                  (89, 320, 2, 89, 320), (290, 32, 2, 290, 32), (336, 77, 3, 104, 271)])
 def test_random_geometries_vs_oracle(vgg_weights, geo):
@@ -463,8 +474,7 @@ def test_random_geometries_vs_oracle(vgg_weights, geo):
             # total-variation term takes - measured 3.4e-3 of the whole gradient (1.7e-2 of the TV term alone), and
             # 4e-7 once the signs are the device's
             closure_vs_oracle_under_equal_decisions(e, xt, tg, vgg_weights, f"geometry {geo} {opts}",
-                                                    terms=(TERMS[0],) if opts == dict(conv_mode="f16x2", batched=True, h2_band_rows=0) else (TERMS[0], TERMS[3]),
-                                                    cap=1e-2)
+                                                    terms=_geometry_terms(geo, opts), cap=1e-2)
             g, l = e.closure(dev(xt), 1e3, 4e5, 1e2)
             res.append((g.cpu().numpy(), l.cpu().numpy()))
         finally:
@@ -584,7 +594,7 @@ def test_level_sharded_closure_adds_up(eng, vgg_weights):
     g_full, l_full = eng.closure(x, 1e3, 4e5, 1e2)
     world = 2
     parts = [eng.closure_levels(x, 1e3, 4e5, 1e2, sharding.level_mask(3, r, world)) for r in range(world)]
-    assert sharding.owned_levels(3, 0, 2) == [0, 2] and sharding.owned_levels(3, 1, 2) == [1]
+    assert sharding.owned_levels(3, 0, 2) == [0] and sharding.owned_levels(3, 1, 2) == [1, 2]       # largest first onto the least-loaded rank
     g_sum = parts[0][0] + parts[1][0]
     l_sum = parts[0][1] + parts[1][1]
     assert rel_l2(g_sum.cpu().numpy(), g_full.cpu().numpy()) < 1e-6

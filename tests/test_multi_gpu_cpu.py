@@ -86,7 +86,7 @@ def test_level_sharding_and_aggregation_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert res["mask0"] == 0b101 and res["mask1"] == 0b010
+    assert res["mask0"] == 0b001 and res["mask1"] == 0b110          # largest first onto the least-loaded rank
     assert res["grad_err"] < 1e-6
     assert res["loss"] == pytest.approx(res["full_loss"], rel=1e-6)
     np.testing.assert_allclose(np.array(res["rows"]), np.array(res["full_rows"]), rtol=1e-6)
@@ -130,3 +130,48 @@ def test_stripe_plan_cut_and_overlap_add_round_trip():
         p.add_into(acc, own)
         cover[p.own[0]:p.own[1]] += 1
     assert torch.equal(acc, img) and torch.equal(cover, torch.ones(H0))
+
+
+def test_levels_are_dealt_by_load():
+    """sharding.deal_levels: largest first onto the least-loaded rank (work of level l = 4**-l)."""
+    from artstyletransfer_amd import sharding
+    assert sharding.deal_levels(range(3), 2) == [[0], [1, 2]]
+    assert sharding.deal_levels(range(4), 2) == [[0], [1, 2, 3]]
+    assert sharding.deal_levels(range(4), 4) == [[0], [1], [2], [3]]                     # BASELINE config 4
+    assert sharding.deal_levels(range(4), 3) == [[0], [1], [2, 3]]
+    assert sharding.deal_levels(range(1, 3), 2) == [[1], [2]]                            # stripes: levels >= 1 only
+    assert sharding.deal_levels(range(1, 4), 2) == [[1], [2, 3]]
+    assert sharding.deal_levels(range(3), 1) == [[0, 1, 2]]
+    for n in range(1, 6):
+        for world in range(1, 9):
+            dealt = sharding.deal_levels(range(n), world)
+            assert sorted(l for part in dealt for l in part) == list(range(n))
+            assert [sharding.owned_levels(n, r, world) for r in range(world)] == dealt
+            masks = [sharding.level_mask(n, r, world) for r in range(world)]
+            assert sum(masks) == (1 << n) - 1 and all(a & b == 0 for i, a in enumerate(masks) for b in masks[i + 1:])
+
+
+def _bench(args, env_extra=None, timeout=300):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True,
+                          timeout=timeout)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` started plainly (no launcher, no WORLD_SIZE) must run TWO ranks, not silently one:
+    the launch path rehearsed over gloo up to the device check (--rendezvous-only leaves before any GPU call)."""
+    import json
+    r = _bench(["--gpus", "2", "--dist-backend", "gloo", "--rendezvous-only"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    rec = json.loads(line)
+    assert rec["n_gpus"] == 2 and rec["ranks_seen"] == 2 and rec["backend"] == "gloo"
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    r = _bench(["--gpus", "2", "--rendezvous-only"], {"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in r.stderr
+    r = _bench(["--gpus", "1", "--rendezvous-only"], {"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "--gpus 1 but WORLD_SIZE=3" in r.stderr
