@@ -263,6 +263,13 @@ def lbfgs_run(e, x, closures, max_eval=1, nlev=3):
     return np.array(rows), steps, moved, xs
 
 
+def first_step(g0, lr=10.0):
+    """s of L-BFGS' first step: t d with d = -g0 and t = min(1, 1/|g0|_1) lr (torch:optim/lbfgs.py:414, :454-457).  NOT
+    x1 - x0: the step is a few ulps of the pixel values, so the difference of the two images is quantisation noise."""
+    t = min(1.0, 1.0 / float(g0.double().abs().sum())) * lr
+    return g0 * (-t)
+
+
 def _fp64_direction(g1, y, s):
     """torch:optim/lbfgs.py:396-442 with ONE curvature pair, in double."""
     g1, y, s = g1.double(), y.double(), s.double()
@@ -304,7 +311,7 @@ def lbfgs_vs_reference_taken_apart(eng, vgg_weights, c_lv, s_lv, x_init, fx, clo
     for k in (0, 1, 2):
         if k == 2 and not moved[1]:
             # step 2 was rejected: the trial point it evaluated is rebuilt from the device's own direction
-            s0, y0 = (xs[1] - xs[0]).reshape(-1), grads[1] - grads[0]
+            s0, y0 = first_step(grads[0]), grads[1] - grads[0]
             ys0 = float(y0.double().dot(s0.double()))
             xs[2] = xs[1] + lr2 * eng.lbfgs_direction(grads[1], [y0], [s0], [1.0 / ys0], ys0 / float(y0.double().dot(y0.double())), 0).view_as(xs[1])
         g, l = eng.closure(xs[k], CW, SW, TVW)
@@ -321,7 +328,7 @@ def lbfgs_vs_reference_taken_apart(eng, vgg_weights, c_lv, s_lv, x_init, fx, clo
         check_rows(l[:-1].cpu().numpy().reshape(NLEV, 4), np.array(ro), 2e-5)
 
     # ---- (2) the step-2 direction from the DEVICE's own (g0, g1, s) against an fp64 recursion, and the iterate it gives
-    s1 = (xs[1] - xs[0]).reshape(-1)
+    s1 = first_step(grads[0])
     y1 = grads[1] - grads[0]
     d64, ys = _fp64_direction(grads[1].cpu(), y1.cpu(), s1.cpu())
     hd = ys / float(y1.double().dot(y1.double()))
@@ -380,7 +387,21 @@ def lbfgs_vs_reference_taken_apart(eng, vgg_weights, c_lv, s_lv, x_init, fx, clo
     # the device's decisions must land where the device lands far closer than the device is to the reference's run (the
     # decisions, not the products, carry the difference) ...
     LAND = 3e-2
-    assert err[3] < LAND and e_dir[3] < LAND and e_land[3] < LAND
+    if moved[1]:
+        # measured on the round-2 start image: device vs the reference's run 2.4e-2, all-direct build vs the device 9.7e-3 -
+        # and the ORACLE under the device's decisions vs the device 8.5e-5: given the same near-tie ReLU / pooling decisions
+        # the reference's arithmetic lands where the device lands
+        assert err[3] < LAND and e_dir[3] < LAND
+        assert e_land[3] < 2e-4, e_land
+    else:
+        # Rejected in the reference's run and here.  Where the first step is as short as it is from the reference's own
+        # start image (y.s within two decades of torch's 1e-10 guard, |g1| / |y| ~ 3e3), the curvature pair is rounding
+        # noise of two gradient evaluations and the two-loop recursion divides by it: the trial point's loss is a number of
+        # the reference's arithmetic on one host, not of the algorithm (measured: reference 1.96e6, the oracle under the
+        # device's decisions 73x that, the device 110x, the all-direct build 310x - every one of them far above f, so every
+        # run rejects the step and keeps the same image).  What is compared is that decision.
+        for trial, kept in ((tot[3], tot[2]), (ref[3], ref[2]), (t2[3], t2[2]), (o_tot[3], o_tot[2])):
+            assert trial > 2.0 * kept
     # ... and the run ends at the reference's loss level
     report(f"{what}: loss at the last accepted point, device {tot[-2] if not moved[-1] else tot[-1]:.6e} vs reference "
            f"{ref[-2] if not moved[-1] else ref[-1]:.6e} (rel {final_err:.2e})")
