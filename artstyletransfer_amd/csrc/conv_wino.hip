@@ -1,7 +1,7 @@
-// conv_wino.hip - the 3x3 convolution (forward: bias + ReLU + ReLU bit mask; input gradient: loss-gradient addend + ReLU mask
-// of the map below) as a 1-D Winograd F(2,3) along x on the fp16 matrix pipe, in the f16x2 arithmetic of conv_h2.hip:
-// 1.5x fewer MFMAs per output.  EXPERIMENT behind nst_options.h2_winograd, for the launches with Cin >= 256, Cout a multiple
-// of 128, no pooling on either side of them and no second (Gram) source.
+// conv_wino.hip - the 3x3 convolution (forward: bias + ReLU + ReLU bit mask + 2x2 max-pool with its arg-max code; input
+// gradient: loss-gradient addend + ReLU mask of the map below, un-pooling loader) as a 1-D Winograd F(2,3) along x on the
+// fp16 matrix pipe, in the f16x2 arithmetic of conv_h2.hip: 1.5x fewer MFMAs per output.  Default (nst_options.h2_winograd)
+// for the launches with Cin >= 256, Cout a multiple of 128 and no second (Gram) source: 14 of the 24 conv launches of a closure.
 //
 // For an output pair (x = 2p, 2p + 1) of a row and the input columns d0..d3 = x - 1 .. x + 2 (one tap row ky):
 //     t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3                    (input transform, fp32, before the cut)
@@ -15,9 +15,13 @@
 // accumulators, exactly conv_h2.hip's products.  Its A fragments (the transformed patch rows of its xi) come from LDS;
 // its B fragments belong to a weight slice no other wave shares beyond the other channel half, so they are loaded
 // L2 -> registers in fragment order (host layout below), two k-steps ahead; LDS holds only the double-buffered patch
-// and there is ONE barrier per chunk (3 stages).  tools/micro/winograd_stream.hip measured this operand stream at 0.87
-// of the both-from-LDS stream's MFMA rate.  The four xi accumulators of a pair live in four waves: the epilogue meets
-// them in LDS (one channel half at a time), applies the output transform, bias and ReLU, and stores 16-byte pieces.
+// and there is ONE barrier per chunk (3 stages).  The patch is fetched ONCE: a staging task loads its pair's own two
+// pixels, takes the transform's outer columns from the neighbouring tasks' registers (ds_bpermute) and only the end pairs
+// load a halo column (round 3: 18 pixel columns per row instead of 32, and the un-pooling loader one pooled pixel per pair
+// instead of four).  The four xi accumulators of a pair live in four waves: the epilogue meets them in LDS, applies the
+// output transform, bias and ReLU, and stores 16-byte pieces.
+// Where a workgroup's time goes and what each stream of the K loop costs: profiles/r03_wino_phase_stamps.txt,
+// profiles/r03_wino_kloop_ablations.txt (tools/micro/wino_probe.hip).
 #include <hip/hip_runtime.h>
 
 #include "nst_kernels.h"
@@ -47,12 +51,6 @@ __device__ unsigned long long g_wino_stamps[(1 << 14) * 8];
 #else
 #define WSTAMP(k)
 #define WSTAMP_REAL(k)
-#endif
-
-// timing-only experiment builds of the probe (WRONG results): bit 0 no weight loads in the K loop, 1 no patch loads, 2 no
-// transform / cut arithmetic, 3 no patch writes to LDS, 4 no A-fragment reads, 5 no barrier
-#ifndef NST_WINO_ABL
-#define NST_WINO_ABL 0
 #endif
 
 namespace {
@@ -101,13 +99,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     // tile of this workgroup
     const int n_ct = b.Cout >> 7;
     const int t = xcd_order((int)blockIdx.x, (int)gridDim.x);
-#if NST_WINO_ABL & 512
-    // output-channel-tile major: a contiguous range of t (one XCD's share) stays on one ct as long as possible
-    const int n_sp = (int)gridDim.x / n_ct;
-    const int ct = t / n_sp, sp_all = t - ct * n_sp;
-#else
     const int sp_all = t / n_ct, ct = t - sp_all * n_ct;
-#endif
     int ii = 0;
     while (ii + 1 < b.n && sp_all >= b.img[ii].tile_end) ++ii;
     ii = __builtin_amdgcn_readfirstlane(ii);      // (provably wave-uniform: the image's pointers then live in scalar registers)
@@ -215,12 +207,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
             u32x2 hi, lo;
-#if NST_WINO_ABL & 4
-            hi = u32x2{__float_as_uint(tt[0][x]), __float_as_uint(E[x])};
-            lo = u32x2{__float_as_uint(O[x]), __float_as_uint(d3[x])};
-#else
             cut2x4(tt[x], sa, hi, lo);
-#endif
             *reinterpret_cast<u32x2*>(base + x * W_PAIRS * W_ROWB) = hi;
             *reinterpret_cast<u32x2*>(base + x * W_PAIRS * W_ROWB + 64) = lo;
         }
@@ -273,14 +260,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
         unsigned char* base = buf + row * W_PROWB + pair * W_ROWB + ch * 2;
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
-#if NST_WINO_ABL & 4
-            const _Float16 hi = __builtin_bit_cast(_Float16, (unsigned short)__float_as_uint(tt[x]));
-            const _Float16 lo = __builtin_bit_cast(_Float16, (unsigned short)(__float_as_uint(tt[x]) >> 16));
-#else
             const float v = tt[x] * sa;
             const _Float16 hi = (_Float16)v;
             const _Float16 lo = (_Float16)((v - (float)hi) * LO_UP);
-#endif
             *reinterpret_cast<_Float16*>(base + x * W_PAIRS * W_ROWB) = hi;
             *reinterpret_cast<_Float16*>(base + x * W_PAIRS * W_ROWB + 64) = lo;
         }
@@ -300,20 +282,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     // B: 16-byte units [ct][chunk][ky][wave][ks][nt][piece][lane]
     struct BF { f16x8 v[2][2]; };       // [n tile][piece]
     auto load_b = [&](BF& f, int chunk, int ky, int ks) {
-#ifdef NST_WINO_ABLATE_WEIGHTS      // timing-only build (wrong results): every stage reads the first 64 KB of the image - cache-hot
-        const int soff = ((wave * 2 + ks) * 4 * 64) * 16 + 0 * (ct + chunk + ky);
-#else
         const int soff = (((((ct * nch + chunk) * 3 + ky) * 8 + wave) * 2 + ks) * 4 * 64) * 16;
-#endif
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-#if NST_WINO_ABL & 64
-                if (s == 1) { f.v[nt][1] = f.v[nt][0]; continue; }      // half the weight bytes
-#endif
-                f.v[nt][s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16 + (nt * 2 + s) * 64 * 16, soff, (NST_WINO_ABL & 256) ? 2 : 0));
-            }
+            for (int s = 0; s < 2; ++s)
+                f.v[nt][s] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lane * 16 + (nt * 2 + s) * 64 * 16, soff, 0));
     };
     auto multiply = [&](const AF& a, const BF& w) {
 #pragma unroll
@@ -359,25 +333,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) {
             // weights two k-steps ahead
-            if (!(NST_WINO_ABL & 1)) {
-                const int q2 = q + ((NST_WINO_ABL & 128) ? 1 : 2);
+            {
+                const int q2 = q + 2;
                 if (q2 < 6) load_b(B[q2 % 3], c, q2 >> 1, q2 & 1);
                 else load_b(B[q2 % 3], cn, (q2 - 6) >> 1, (q2 - 6) & 1);
             }
-            if (!(NST_WINO_ABL & 2)) {
-                if (q == 0) task_load(d, to, cn);
-                if (q == 1) row_load(d1, to, cn);
-            }
+            if (q == 0) task_load(d, to, cn);
+            if (q == 1) row_load(d1, to, cn);
             // next k-step's A fragments
-            if (!(NST_WINO_ABL & 16) && q + 1 < 6) read_a(A[(q + 1) & 1], cur, (q + 1) >> 1, (q + 1) & 1);
+            if (q + 1 < 6) read_a(A[(q + 1) & 1], cur, (q + 1) >> 1, (q + 1) & 1);
             multiply(A[q & 1], B[q % 3]);
-            if (!(NST_WINO_ABL & 8)) {
-                if (q == 4) task_store(d, to, nxt);
-                if (q == 5) row_store(d1, to, nxt);
-            }
+            if (q == 4) task_store(d, to, nxt);
+            if (q == 5) row_store(d1, to, nxt);
         }
-        if (!(NST_WINO_ABL & 32)) __syncthreads();
-        if (!(NST_WINO_ABL & 16) && c + 1 < nch) read_a(A[0], nxt, 0, 0);
+        __syncthreads();
+        if (c + 1 < nch) read_a(A[0], nxt, 0, 0);
     }
 
     WSTAMP(2);

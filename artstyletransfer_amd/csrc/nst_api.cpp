@@ -114,6 +114,8 @@ struct nst_ctx {
     int level_split = 0;        // nst_options.level_split
     hipStream_t side = nullptr; // the Gram launches of the shallow style layers run here, under the deeper forward convolutions
     hipEvent_t side_fork = nullptr, side_join = nullptr;
+    hipStream_t tail_stream = nullptr;   // the stream the tail event was last recorded on (see enter())
+    bool tail_set = false;
     hipEvent_t tail = nullptr;  // recorded after the last launch that touches context-owned memory: what
                                 // nst_job_configure / nst_ctx_destroy wait for instead of the whole device
     int batched = 1;            // 1: one conv launch per layer covering every pyramid level (one stream)
@@ -906,7 +908,17 @@ int bind(nst_ctx* ctx) {
 // Remember where the context's work ends: an event on the caller's stream after the last launch of an entry point that
 // reads or writes context-owned memory.
 void mark(nst_ctx* ctx, hipStream_t s) {
-    if (ctx && ctx->tail) (void)hipEventRecord(ctx->tail, s);
+    if (ctx && ctx->tail && hipEventRecord(ctx->tail, s) == hipSuccess) { ctx->tail_stream = s; ctx->tail_set = true; }
+}
+// The entry points that read or write context-owned memory (targets, workspace, level images) are ordered as they are
+// issued, whatever stream each is issued on: a call on ANOTHER stream than the previous one first makes its stream wait for
+// the context's tail event.  One tail event then covers everything the context has in flight - what nst_job_configure and
+// nst_ctx_destroy wait for before they free the workspace - without relying on hipFree's implicit synchronisation, and a
+// read-back issued on a second stream (nst_level_image after nst_closure) sees the closure's results.
+hipStream_t enter(nst_ctx* ctx, void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (ctx->tail_set && s != ctx->tail_stream) (void)hipStreamWaitEvent(s, ctx->tail, 0);
+    return s;
 }
 // Wait until nothing on the device uses the context's memory any more: its tail event and its own streams - NOT
 // hipDeviceSynchronize, which would stall the other job sharing the GPU (two jobs per GPU is the scheduler's default).
@@ -1161,16 +1173,27 @@ int nst_job_configure(nst_ctx* ctx, int levels_num, int H0, int W0) {
     return NST_OK;
 }
 
+static bool batch_eligible(const nst_ctx* ctx);
 int nst_level_set_targets(nst_ctx* ctx, int level, const float* content, const float* style, int hs, int ws,
                           void* stream) {
     NSTCHK(bind(ctx));
     if (level < 0 || level >= ctx->levels) return fail(ctx, NST_E_STATE, "level not configured");
     if (!content || !style) return fail(ctx, NST_E_ARG, "null image");
     if (hs < 16 || ws < 16) return fail(ctx, NST_E_ARG, "style image must be at least 16x16");
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStream_t s = enter(ctx, stream);
     LevelWs& L = ctx->lv[level];
-    // content: ReLU(conv4_2) of the content image, through the level's own activation buffers
-    NSTCHK(forward(ctx, L.acts, content, L.h, L.w, s, kContentLayer));
+    // content: ReLU(conv4_2) of the content image, through the level's own activation buffers - by the launches the closure
+    // of this job will use (one launch per layer, Winograd F(2,3) where it applies), so that target and current features
+    // carry the same rounding: an image that IS the content image then has a content loss of (all but) exactly zero, as in
+    // the reference, whose target and current features come from one and the same forward code
+    if (batch_eligible(ctx)) {
+        const float* xi[NST_MAX_LEVELS] = {};
+        xi[level] = content;
+        const int lv1 = level;
+        NSTCHK(batched_forward(ctx, xi, &lv1, 1, s, nullptr));
+    } else {
+        NSTCHK(forward(ctx, L.acts, content, L.h, L.w, s, kContentLayer));
+    }
     HIPCHK(ctx, hipMemcpyAsync(L.content_t, L.acts.act[kContentLayer], L.content_n * 4, hipMemcpyDeviceToDevice, s));
     // style: 5 Gram matrices of the style image (its own size)
     ActSet sa;
@@ -1226,7 +1249,7 @@ int nst_closure_levels(nst_ctx* ctx, const float* x, float cw, float sw, float t
     for (int i = 0; i < ctx->levels; ++i)
         if (((level_mask >> i) & 1u) && !ctx->lv[i].targets)
             return fail(ctx, NST_E_STATE, "targets of level " + std::to_string(i) + " not set");
-    hipStream_t main = static_cast<hipStream_t>(stream);
+    hipStream_t main = enter(ctx, stream);
     if (ctx->timing >= 2) NSTCHK(fold_timed(ctx));
     ctx->timed.clear();
     ctx->ev_used = 0;
@@ -1396,7 +1419,7 @@ int nst_window_begin(nst_ctx* ctx, const float* xs, int row0, int rows, int H0, 
     NSTCHK(bind(ctx));
     NSTCHK(window_check(ctx, xs, row0, rows, H0));
     if (!sums) return fail(ctx, NST_E_ARG, "null buffer");
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStream_t s = enter(ctx, stream);
     LevelWs& L = ctx->lv[0];
     ActSet& a = L.acts;
     Window win{row0, rows, H0, sums};
@@ -1433,7 +1456,7 @@ int nst_window_end(nst_ctx* ctx, const float* xs, int row0, int rows, int H0, fl
     NSTCHK(bind(ctx));
     NSTCHK(window_check(ctx, xs, row0, rows, H0));
     if (!sums || !gxs || !losses) return fail(ctx, NST_E_ARG, "null buffer");
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStream_t s = enter(ctx, stream);
     LevelWs& L = ctx->lv[0];
     ActSet& a = L.acts;
     Window win{row0, rows, H0, sums};
@@ -1575,7 +1598,7 @@ int nst_level_activation(nst_ctx* ctx, int level, int layer, float* out, void* s
     if (level < 0 || level >= ctx->levels) return fail(ctx, NST_E_STATE, "level not configured");
     if (layer < 0 || layer >= NL || !out) return fail(ctx, NST_E_ARG, "bad argument");
     const ActSet& a = ctx->lv[level].acts;
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStream_t s = enter(ctx, stream);
     HIPCHK(ctx, launch_hwc_to_chw(a.act[layer], kCout[layer], a.h[layer], a.w[layer], out, s));
     mark(ctx, s);
     return NST_OK;
@@ -1586,7 +1609,7 @@ int nst_level_image(nst_ctx* ctx, int level, float* out, void* stream) {
     if (level < 1 || level >= ctx->levels) return fail(ctx, NST_E_ARG, "level must be 1 .. levels_num - 1 (level 0 is the caller's x)");
     if (!out) return fail(ctx, NST_E_ARG, "null argument");
     const LevelWs& L = ctx->lv[level];
-    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipStream_t s = enter(ctx, stream);
     HIPCHK(ctx, hipMemcpyAsync(out, L.xl, (size_t)3 * L.h * L.w * sizeof(float), hipMemcpyDeviceToDevice, s));
     mark(ctx, s);
     return NST_OK;

@@ -64,6 +64,9 @@ struct nst_opt {
     float* pool = nullptr;       // ONE allocation made by nst_opt_create holding every history vector (2*history + 2
                                  // of them): no hipMalloc - an implicit device synchronisation - inside a step
     hipEvent_t tail = nullptr;   // recorded after the last launch of every step: what nst_opt_destroy waits for
+    hipStream_t tail_stream = nullptr;
+    bool tail_set = false;
+    bool want_rows = false;      // this step keeps the loss rows of its closures for the caller
     bool H_is_one = true; float H_diag = 1.f;
     bool t_is_float = true;      // t held as fp32 tensor value vs python double
     double t = 0.0;
@@ -649,17 +652,10 @@ int nst_lbfgs_direction(nst_ctx* ctx, const float* g, const float* const* y, con
     return rc;
 }
 
-int nst_opt_step(nst_opt* o, float* x, float cw, float sw, float tvw, float* losses_host, int closures_capacity,
-                 nst_step_info* info, void* stream) {
-    if (!o || !x || !info) return nst_internal_fail(o ? o->ctx : nullptr, NST_E_ARG, "null argument");
-    if (hipSetDevice(nst_internal_device(o->ctx)) != hipSuccess) return nst_internal_fail(o->ctx, NST_E_HIP, "hipSetDevice failed");
-    hipStream_t s = static_cast<hipStream_t>(stream);
-    std::memset(info, 0, sizeof(*info));
-    o->loss_rows.clear();
-    const int before = o->total_closures;
+static int opt_step_body(nst_opt* o, float* x, float cw, float sw, float tvw, nst_step_info* info, hipStream_t s) {
     if (o->kind == NST_OPT_ADAM) {
         float loss = NAN;
-        if (losses_host) {
+        if (o->want_rows) {
             OCHK(eval_closure(o, x, cw, sw, tvw, s, &loss));
         } else {
             o->lr *= 0.999;
@@ -675,7 +671,25 @@ int nst_opt_step(nst_opt* o, float* x, float cw, float sw, float tvw, float* los
     } else {
         OCHK(lbfgs_step(o, x, cw, sw, tvw, s, info));
     }
-    OHIP(o, hipEventRecord(o->tail, s));
+    return NST_OK;
+}
+
+int nst_opt_step(nst_opt* o, float* x, float cw, float sw, float tvw, float* losses_host, int closures_capacity,
+                 nst_step_info* info, void* stream) {
+    if (!o || !x || !info) return nst_internal_fail(o ? o->ctx : nullptr, NST_E_ARG, "null argument");
+    if (hipSetDevice(nst_internal_device(o->ctx)) != hipSuccess) return nst_internal_fail(o->ctx, NST_E_HIP, "hipSetDevice failed");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // a step issued on another stream than the previous one is ordered behind it (one tail event then covers the optimiser)
+    if (o->tail_set && s != o->tail_stream) OHIP(o, hipStreamWaitEvent(s, o->tail, 0));
+    std::memset(info, 0, sizeof(*info));
+    o->loss_rows.clear();
+    const int before = o->total_closures;
+    o->want_rows = losses_host != nullptr;
+    const int rc = opt_step_body(o, x, cw, sw, tvw, info, s);
+    // recorded on EVERY path out of the step - a step that failed half way has launches in flight too - so that
+    // nst_opt_destroy never frees the optimiser's buffers under them
+    if (hipEventRecord(o->tail, s) == hipSuccess) { o->tail_stream = s; o->tail_set = true; }
+    if (rc != NST_OK) return rc;
     info->closures = o->total_closures - before;
     info->total_closures = o->total_closures;
     info->lr = (float)o->lr;

@@ -73,6 +73,7 @@ class StyleEngine:
         ctx = C.c_void_p()
         _lib.check(None, self.lib.nst_ctx_create_ex(idx, wp, bp, C.byref(opts), C.byref(ctx)), "nst_ctx_create_ex")
         self.ctx = ctx
+        self.weights_id = id(weights)          # which weight set this context carries (neural_nets' engine pool)
         self.levels = 0
         self.shape = None
 
@@ -92,6 +93,11 @@ class StyleEngine:
         _lib.check(self.ctx, self.lib.nst_job_configure(self.ctx, levels_num, H0, W0), "nst_job_configure")
         self.levels = levels_num
         self.shape = (H0, W0)
+
+    def release_job(self) -> None:
+        """Give the job's pyramid workspace back (4.7 GB at L=2) and keep the context with its uploaded weights: what an
+        engine waiting in neural_nets' pool holds is the smallest job nst_job_configure accepts."""
+        self.configure(1, 16, 16)
 
     def level_shape(self, level: int) -> Tuple[int, int]:
         h, w = self.shape

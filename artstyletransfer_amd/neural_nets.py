@@ -88,6 +88,46 @@ def set_weights(weights) -> None:
         for e in _engines.values():
             e.close()
         _engines.clear()
+        for pool in _idle.values():
+            for e in pool:
+                e.close()
+        _idle.clear()
+
+
+_idle: Dict[int, List[StyleEngine]] = {}       # engines (contexts with the weights uploaded) waiting for their next job, per GPU
+_IDLE_MAX = 2                                  # config.simultaneous_tasks_count jobs per GPU is the scheduler's default
+
+
+def lease_engine(device) -> StyleEngine:
+    """An engine for ONE job's targets and workspace (a LossBuilder, a job of the loop).  Contexts are re-used: building
+    one means re-laying out and uploading 13 layers of weights (0.25 s, 260 MB), configuring one for the next job only
+    re-allocates the pyramid workspace.  Give it back with `return_engine`."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    with _lock:
+        pool = _idle.get(idx)
+        if pool:
+            return pool.pop()
+    return StyleEngine(load_weights(), idx)
+
+
+def return_engine(eng: StyleEngine) -> None:
+    if getattr(eng, "ctx", None) is None:
+        return
+    idx = eng.device.index
+    with _lock:
+        pool = _idle.setdefault(idx, [])
+        keep = len(pool) < _IDLE_MAX and _weights_cache is not None and getattr(eng, "weights_id", None) == id(_weights_cache)
+    if keep:
+        try:
+            eng.release_job()                  # the workspace goes back now, only the weights stay resident
+        except Exception:
+            keep = False
+    if keep:
+        with _lock:
+            _idle.setdefault(idx, []).append(eng)
+        return
+    eng.close()
 
 
 def shared_engine(device) -> StyleEngine:

@@ -18,7 +18,7 @@ import torch
 
 from . import device_image, host_image, math_utils
 from .engine import PixelOptimizer, StyleEngine
-from .neural_nets import load_weights, shared_engine
+from .neural_nets import lease_engine, return_engine, shared_engine
 
 # ImageNet statistics (reference :22-23)
 IMAGENET_MEAN_255 = [123.675, 116.28, 103.53]
@@ -82,9 +82,17 @@ class LossBuilder:
             raise ValueError("the HIP closure implements the reference's VGG19 taps (content 4, style [0,1,2,3,5])")
         self.__weights = (float(content_weight), float(style_weight), float(tv_weight))
         c = target_content_image
-        self.__engine = StyleEngine(load_weights(), c.device)
+        # a context from the per-GPU pool (the weights are uploaded once, not per LossBuilder); it goes back when this
+        # object is collected
+        self.__engine = lease_engine(c.device)
         self.__engine.configure(1, c.shape[-2], c.shape[-1])
         self.__engine.set_targets(0, c.contiguous(), target_style_image.contiguous())
+
+    def __del__(self):
+        try:
+            return_engine(self.__engine)
+        except Exception:
+            pass
 
     def build(self, optimizing_img):
         cw, sw, tvw = self.__weights
@@ -102,7 +110,7 @@ class _DeviceJob:
     def __init__(self, device, optimizer_name, style_imgs, content_imgs, init_img, lr_start):
         self.dev = dev = device
         self.optimizer = None
-        self.engine = StyleEngine(load_weights(), dev)
+        self.engine = lease_engine(dev)
         h0, w0 = init_img.shape[:2]
         # Every job runs on a HIP stream of its own: the jobs that share a GPU (`config.simultaneous_tasks_count`
         # per GPU, as in the reference) then overlap on the device - one job's launch tails, host round trips and
@@ -168,7 +176,7 @@ class _DeviceJob:
             self.optimizer = None
         self.job_stream.synchronize()
         self.copy_stream.synchronize()
-        self.engine.close()
+        return_engine(self.engine)             # back to the per-GPU pool: the next job re-uses its uploaded weights
 
 
 def _make_job(device, optimizer_name, style_imgs, content_imgs, init_img, lr_start):

@@ -797,6 +797,27 @@ def test_device_pyramid_and_noise_init_vs_oracle(eng):
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("opts", [dict(), dict(h2_winograd=False), dict(conv_mode="f32")])
+def test_content_image_as_start_has_no_content_loss(vgg_weights, opts):
+    """The reference's target and current features come from the same forward code, so an optimised image that IS the
+    content image (init_method 'content' at level 0) starts with a content loss of exactly 0.  Here the content target is
+    built by the launches the closure uses (nst_level_set_targets: one launch per layer, Winograd F(2,3) where it applies):
+    the level-0 content term must vanish against the total, in the default build, with every convolution direct, and on
+    the exact-f32 engine."""
+    from artstyletransfer_amd.engine import StyleEngine
+    c, s = _levels(256, 384, 2, 1), _levels(200, 280, 2, 2)
+    e = StyleEngine(vgg_weights, 0, **opts)
+    try:
+        _setup(e, c, s)
+        _, l = e.closure(dev(cpu_ref.prepare_img(c[0])), 1e3, 4e5, 1e2)
+        rows = l.cpu().numpy()[:-1].reshape(2, 4).astype(np.float64)
+        share = 1e3 * rows[0, 1] / rows[0, 0]
+        report(f"content image as the start {opts}: level-0 content loss {rows[0, 1]:.3e} = {share:.1e} of the level total")
+        assert share < 1e-10
+    finally:
+        e.close()
+
+
 def _jobsetup_cases():
     import os
     import sys
