@@ -450,13 +450,18 @@ class PixelOptimizer:
                                                      _ptr(self._g), _ptr(self._l), self._hook, None),
                    "nst_opt_shard_levels")
 
-    def shard_stripes(self, rank: int, world: int, weights, content_t: torch.Tensor, style_t: torch.Tensor,
+    def shard_stripes(self, rank: int, world: int, weights, content_t, style_t,
                       dist_mod=None, group=None, comm: "Communicator" = None) -> None:
-        """Spatial sharding of the top level (SURVEY 8(e) partition B, halo recompute) on top of level sharding of the
-        rest: every rank evaluates a horizontal stripe of level 0 (its rows + a 96-row halo, a second engine) and its
-        share of the lower levels.  Per closure: one all-reduce of the Gram / content / TV sums between the stripe's
-        forward and backward pass, one of the pixel gradient and the loss rows at the end.  content_t / style_t: the
-        prepared (1,3,H0,W0) content and (1,3,hs,ws) style images of level 0.
+        """Spatial sharding of the large levels (SURVEY 8(e) partition B, halo recompute) on top of level sharding of the
+        rest: every rank evaluates a horizontal stripe (its rows + a 96-row halo, a single-level engine of its own) of
+        every STRIPED level and its share of the other levels.  content_t / style_t: the prepared (1,3,h,w) content and
+        (1,3,hs,ws) style images of the striped levels, level 0 first - a tensor (level 0 only, 75 % of the work) or a
+        list (levels 0, 1, ...: with level 1 striped as well 94 % of the work is cut evenly).  Per closure: ONE
+        all-reduce of the Gram / content / TV sums of all striped levels between the stripes' forward and backward passes,
+        one of the pixel gradient and the loss rows at the end.  A striped level l >= 1 works on the rows of
+        x_l = D^l x (the whole down-sampled image is formed on every rank: HBM-bound, 1/4 of the pixels) and hands its
+        partial gradient back through the transpose of the down-sampling, which is linear - the final all-reduce sums the
+        ranks' parts.
         `comm` (a Communicator): both collectives go through the C ABI's RCCL communicator (nst_comm_allreduce_sum on
         the job's stream; gradient and loss row are ONE packed buffer, as in nst_opt_shard_levels_comm) and rank / world
         are the communicator's; otherwise through `dist_mod` (torch.distributed: gloo rehearsals, or nccl)."""
@@ -465,35 +470,59 @@ class PixelOptimizer:
             rank, world = comm.rank, comm.world
         elif dist_mod is None:
             import torch.distributed as dist_mod
+        contents = list(content_t) if isinstance(content_t, (list, tuple)) else [content_t]
+        styles = list(style_t) if isinstance(style_t, (list, tuple)) else [style_t]
         e = self.engine
         H, W = e.shape
-        plan = sharding.StripePlan(H, world, rank)
-        stripe = StyleEngine(weights, e.device)
-        stripe.configure(1, plan.ext_rows, W)
-        stripe.set_targets(0, plan.cut(content_t), style_t.contiguous())
-        self._stripe, self._plan = stripe, plan
+        nstriped = min(len(contents), len(styles), e.levels)
+        plans, stripes = [], []
+        for l in range(nstriped):
+            plan = sharding.StripePlan(H >> l, world, rank)
+            st = StyleEngine(weights, e.device)
+            st.configure(1, plan.ext_rows, W >> l)
+            st.set_targets(0, plan.cut(contents[l]), styles[l].contiguous())
+            plans.append(plan)
+            stripes.append(st)
+        self._stripes, self._plans = stripes, plans
+        self._stripe, self._plan = stripes[0], plans[0]
         n = 3 * H * W
         self._pack = torch.zeros(n + self.row, dtype=torch.float32, device=e.device)
         self._g = self._pack[:n].view(1, 3, H, W)
         self._l = self._pack[n:]
-        # lower levels: dealt largest first onto the least-loaded rank (every rank carries an equal stripe of level 0);
-        # level 0 is nobody's in the level mask (its stripes are added here)
+        count = stripes[0].window_sums_count()
+        sums_all = torch.empty(nstriped * count, dtype=torch.float32, device=e.device)
+        # the other levels: dealt largest first onto the least-loaded rank (every rank carries an equal stripe of the
+        # striped levels); a striped level is nobody's in the level mask (its stripes are added here)
         mask = 0
-        for l in sharding.deal_levels(range(1, e.levels), world)[rank]:
+        for l in sharding.deal_levels(range(nstriped, e.levels), world)[rank]:
             mask |= 1 << l
 
         def hook(_user):
             x, (cw, sw, tvw) = self._x, self._w
-            xs = plan.cut(x)
-            sums = stripe.window_begin(xs, plan.row0, plan.rows, H)
+            imgs, cuts = [x], []
+            for l in range(nstriped):
+                if l > 0:
+                    imgs.append(e.bicubic_half(imgs[-1]))               # x_l = D x_{l-1}, whole image
+                xs = plans[l].cut(imgs[l])
+                cuts.append(xs)
+                stripes[l].window_begin(xs, plans[l].row0, plans[l].rows, H >> l, sums_all[l * count:(l + 1) * count])
             if comm is not None:
-                comm.allreduce_sum(sums)
+                comm.allreduce_sum(sums_all)
             else:
-                dist_mod.all_reduce(sums, op=dist_mod.ReduceOp.SUM, group=group)
-            gxs, row = stripe.window_end(xs, plan.row0, plan.rows, H, cw, sw, tvw, sums)
-            plan.add_into(self._g, gxs)
-            if rank == 0:                      # every rank holds the same level-0 row: one contributor
-                self._l[0:4] = row[0:4]
+                dist_mod.all_reduce(sums_all, op=dist_mod.ReduceOp.SUM, group=group)
+            for l in range(nstriped):
+                gxs, row = stripes[l].window_end(cuts[l], plans[l].row0, plans[l].rows, H >> l, cw, sw, tvw,
+                                                 sums_all[l * count:(l + 1) * count])
+                if l == 0:
+                    plans[0].add_into(self._g, gxs)
+                else:
+                    gl = torch.zeros_like(imgs[l])
+                    plans[l].add_into(gl, gxs)
+                    for k in range(l, 0, -1):                           # back through the down-sampling chain: D^T
+                        gl = e.bicubic_half_backward(gl, H >> (k - 1), W >> (k - 1))
+                    self._g += gl
+                if rank == 0:                  # every rank holds the same row of a striped level: one contributor
+                    self._l[4 * l:4 * l + 4] = row[0:4]
             if comm is not None:
                 comm.allreduce_sum(self._pack)
                 sharding.reform_total(self._l)
@@ -520,6 +549,9 @@ class PixelOptimizer:
         if getattr(self, "h", None) and getattr(self.engine, "ctx", None):
             self.engine.lib.nst_opt_destroy(self.h)
         self.h = None
+        for st in getattr(self, "_stripes", ()):       # the stripe engines of shard_stripes
+            st.close()
+        self._stripes = []
 
     def __del__(self):
         try:

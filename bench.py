@@ -380,6 +380,9 @@ def main():
                     help="mode 'jobs' only: that many independent jobs per GPU, each on its own HIP stream and host "
                          "thread (the scheduler's simultaneous_tasks_count; 2 gives ~1.09x the aggregate rate). The "
                          "default, 1, is the configuration BASELINE quotes")
+    ap.add_argument("--stripe-levels", type=int, default=2,
+                    help="mode 'stripes': how many of the top levels are cut into stripes (level 0 = 75 %% of the work, "
+                         "levels 0-1 = 94 %%); the rest is dealt out by level")
     ap.add_argument("--mode", default="jobs", choices=["jobs", "levels", "stripes"],
                     help="N>1: 'jobs' = one independent job per GPU (weak scaling, no collective); 'levels' = ONE "
                          "job, pyramid levels sharded over the ranks, RCCL all-reduce of the pixel gradient per "
@@ -446,7 +449,9 @@ def main():
             opt.shard_levels(rank, world, dist)
     elif sharded:
         # the top level cut into horizontal stripes (+ halo), the lower levels dealt out by level
-        opt.shard_stripes(rank, world, job_host[3], prep(job_host[0][0]), prep(job_host[1][0]), dist, comm=comm)
+        ns = min(args.stripe_levels, args.levels)
+        opt.shard_stripes(rank, world, job_host[3], [prep(job_host[0][l]) for l in range(ns)],
+                          [prep(job_host[1][l]) for l in range(ns)], dist, comm=comm)
     w3 = (cfg.content_weight, cfg.style_weight, cfg.tv_weight)
     cw, sw, tvw = w3
     H, W = eng.shape
@@ -538,7 +543,7 @@ def main():
                                        (f"levels sharded over {world} ranks, one RCCL all-reduce of the packed pixel gradient + loss row per closure"
                                         + (" behind the C ABI (nst_comm)" if comm is not None else " through torch.distributed")
                                         if args.mode == "levels" else
-                                        f"top level in {world} stripes (+96-row halo), lower levels by level; all-reduce of the "
+                                        f"top {min(args.stripe_levels, args.levels)} level(s) in {world} stripes (+96-row halo), lower levels by level; all-reduce of the "
                                         f"Gram/content/TV sums and of the packed pixel gradient + loss row per closure"
                                         + (" behind the C ABI (nst_comm)" if comm is not None else " through torch.distributed"))
                                        if sharded else (f"{args.jobs_per_gpu} job(s) per GPU on their own streams, no collective" if args.jobs_per_gpu > 1 else "1 job per GPU, no collective")),

@@ -301,6 +301,32 @@ def test_stripe_sharding_through_the_c_communicator_world_of_one():
     assert "comm (rank, world, calls, bytes) (0, 1," in out.stdout
 
 
+@pytest.mark.parametrize("world,levels_num,mode", [(2, 3, "stripes"), (4, 4, "stripes"), (4, 4, "levels")])
+def test_sharded_job_rehearsed_over_gloo_on_one_gpu(world, levels_num, mode):
+    """The N > 1 forms of ONE job rehearsed on this one-GPU box: `world` ranks share cuda:0, the collectives go through
+    torch.distributed over gloo (tools/check_sharded_opt.py).  (4, 4): BASELINE config 4's exact geometry - L=3,
+    levels_num = 4, 3072x2048 - on 4 ranks, by levels (partition A) and by stripes of levels 0 AND 1 with the lower levels
+    dealt by load (partition B).  Asserted by the tool: the accept / reject sequence of the sharded optimiser is the
+    unsharded one's; by levels the loss rows and the pixel checksum are bit-identical, by stripes the rows of the first
+    closures agree to 1e-5 and the pixel checksum to 1e-9."""
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", NST_SYNTHETIC_WEIGHTS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "tools", "check_sharded_opt.py"), mode, "--backend", "gloo", "--share-gpu",
+           "--levels", str(levels_num), "--steps", "3"]
+    out = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "SHARDED == UNSHARDED" in out.stdout and f"world {world} {mode}" in out.stdout
+
+
 @pytest.mark.parametrize("mode", ["levels", "stripes"])
 def test_sharded_job_over_rccl_matches_the_unsharded_job(mode):
     """Two ranks on two GPUs over RCCL (skipped on a one-GPU box): tools/check_sharded_opt.py runs the optimiser sharded
