@@ -87,7 +87,11 @@ __device__ __forceinline__ int xcd_order(const int b, const int grid) {
 
 // UNPOOL: every image's `in` is the gradient w.r.t. a 2x2-pooled map; the loader un-pools it through the arg-max code words
 // (conv_h2.hip's rule: [pooled pixel][32-channel group][window position], bit = channel & 31).
-template <bool UNPOOL>
+// MODE: what the epilogue may meet - 1: a forward launch (bias + ReLU, ReLU bit mask, pooled map + arg-max code; no addend, no
+// incoming mask), 2: an input-gradient launch (addend, ReLU mask of the map below; nothing of the former), 0: anything.  The
+// launcher picks 1 or 2 where the launch fits: the epilogue is bound by its vector instructions (profiles/
+// r03_wino_phase_stamps.txt: 8 k cycles of an 80 k-cycle tile), and the specialised forms shed the other form's selects.
+template <bool UNPOOL, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,7 +103,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     // tile of this workgroup
     const int n_ct = b.Cout >> 7;
     const int t = xcd_order((int)blockIdx.x, (int)gridDim.x);
-    const int sp_all = t / n_ct, ct = t - sp_all * n_ct;
+    // Which (spatial tile, output-channel tile) the t-th workgroup of the XCD-contiguous order takes.  Up to 256 output
+    // channels the layer's whole weight image (3.1 MB) stays in an XCD's L2 beside the patch stream: the n_ct channel tiles
+    // of a patch are neighbours in t and share its lines.  A 512-channel layer's image is 12.6 MB - walked by every XCD
+    // in every round of workgroups it comes back from the Infinity Cache each time (0.4 GB per launch) - so there the
+    // order is channel-tile major: an XCD's share of t stays on ONE 3.1-MB slice (the patch is then fetched by n_ct XCDs:
+    // 70 MB per launch).  Speed: the same (profiles/r03_wino_kloop_ablations.txt); fabric traffic: see DESIGN 6.
+    int sp_all, ct;
+    if (n_ct >= 4) {
+        const int n_sp = (int)gridDim.x / n_ct;
+        ct = t / n_sp;
+        sp_all = t - ct * n_sp;
+    } else {
+        sp_all = t / n_ct;
+        ct = t - sp_all * n_ct;
+    }
     int ii = 0;
     while (ii + 1 < b.n && sp_all >= b.img[ii].tile_end) ++ii;
     ii = __builtin_amdgcn_readfirstlane(ii);      // (provably wave-uniform: the image's pointers then live in scalar registers)
@@ -354,12 +372,36 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     // ---- epilogue: the four xi accumulators of every pair meet in LDS, one output-channel half at a time.  A thread then
     // owns a 2x2 pixel window (image rows 2 yp, 2 yp + 1 of the tile, output pair p) x 4 channels: output transform, bias /
     // addend, ReLU / ReLU mask, 16-byte stores, and - where a pooling layer follows - the window's maximum and arg-max code.
+    constexpr bool M_FWD = MODE != 2, M_BWD = MODE != 1;      // what this instantiation has to handle
+    const float* const e_bias = M_FWD ? b.bias : nullptr;
+    const bool e_relu = MODE == 0 ? (b.relu != 0) : (MODE == 1);
+    unsigned* const e_bits_out = M_FWD ? im.bits_out : nullptr;
+    float* const e_pool_out = M_FWD ? im.pool_out : nullptr;
+    unsigned* const e_pcode_out = M_FWD ? im.pcode_out : nullptr;
+    const float* const e_addend = M_BWD ? im.addend : nullptr;
+    const unsigned* const e_bits_in = M_BWD ? im.bits_in : nullptr;
     float* E = reinterpret_cast<float*>(smem);                               // [xi][pair row 64][128]
     unsigned* WB = reinterpret_cast<unsigned*>(smem + W_BITS_OFF);           // [pixel 128][4 words]
     unsigned* PC = reinterpret_cast<unsigned*>(smem + W_CODE_OFF);           // [pooled pixel 32][4 words][4 positions]
     const int words = Cout >> 5;
     float amax = 0.f;
     const int yp = tid >> 7, p = (tid >> 4) & 7, cq = tid & 15;
+    // what the output pass reads from global memory is requested here, ahead of the exchange through LDS: the bias of this
+    // thread's channels (both passes) and, in an input-gradient launch, the ReLU-mask words of its 2 x 2 pixels
+    f32x4 bvp[2];
+    unsigned mw[2][2][2];
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const int co = n0 + pass * 64 + cq * 4;
+        bvp[pass] = e_bias ? *reinterpret_cast<const f32x4*>(e_bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int gy = y0 + 2 * yp + k, gx = x0 + 2 * p;
+            const size_t pa = (size_t)gy * W + gx;
+            mw[pass][k][0] = (e_bits_in && gy < H && gx < W) ? e_bits_in[pa * (Cout >> 5) + (co >> 5)] : 0u;
+            mw[pass][k][1] = (e_bits_in && gy < H && gx + 1 < W) ? e_bits_in[(pa + 1) * (Cout >> 5) + (co >> 5)] : 0u;
+        }
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -369,13 +411,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * half;      // row of the 32-row tile
                 E[(xi * 64 + mt * 32 + m) * 128 + wn * 64 + nt * 32 + l31] = fmaf(accx[mt][nt][r], LO_DOWN, accm[mt][nt][r]) * inv;
             }
-    if (im.bits_out) WB[tid] = 0u;
-    if (im.pcode_out) PC[tid] = 0u;
+    if (e_bits_out) WB[tid] = 0u;
+    if (e_pcode_out) PC[tid] = 0u;
     __syncthreads();
     WSTAMP(3);
     for (int pass = 0; pass < 2; ++pass) {      // the two 64-channel halves of the tile, one after the other per thread
         const int co = n0 + pass * 64 + cq * 4;
-        const f32x4 bv = b.bias ? *reinterpret_cast<const f32x4*>(b.bias + co) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4 bv = bvp[pass];
         const int w = pass * 2 + (cq >> 3), sh = (cq & 7) * 4;
         f32x4 win[2][2];                  // [row of the window][column]
 #pragma unroll
@@ -391,19 +433,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
             const size_t pa = (size_t)gy * W + gx;
             // input-gradient launches: the loss gradient injected at this layer (content), then the ReLU mask of the map
             // this gradient belongs to (one bit per channel, 32 channels per word)
-            if (im.addend) {
-                if (ina) ya += *reinterpret_cast<const f32x4*>(im.addend + pa * Cout + co);
-                if (inb) yb += *reinterpret_cast<const f32x4*>(im.addend + (pa + 1) * Cout + co);
+            if (e_addend) {
+                if (ina) ya += *reinterpret_cast<const f32x4*>(e_addend + pa * Cout + co);
+                if (inb) yb += *reinterpret_cast<const f32x4*>(e_addend + (pa + 1) * Cout + co);
             }
             unsigned ka = 0xFu, kb = 0xFu;
-            if (im.bits_in) {
-                ka = ina ? (im.bits_in[pa * words + (co >> 5)] >> (co & 31)) & 0xFu : 0u;
-                kb = inb ? (im.bits_in[(pa + 1) * words + (co >> 5)] >> (co & 31)) & 0xFu : 0u;
+            if (e_bits_in) {
+                ka = (mw[pass][k][0] >> (co & 31)) & 0xFu;
+                kb = (mw[pass][k][1] >> (co & 31)) & 0xFu;
             }
             unsigned na = 0u, nb = 0u;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                if (b.relu) { ya[e] = fmaxf(ya[e], 0.f); yb[e] = fmaxf(yb[e], 0.f); }
+                if (e_relu) { ya[e] = fmaxf(ya[e], 0.f); yb[e] = fmaxf(yb[e], 0.f); }
                 ya[e] = ((ka >> e) & 1u) ? ya[e] : 0.f;
                 yb[e] = ((kb >> e) & 1u) ? yb[e] : 0.f;
                 na |= (ya[e] > 0.f ? 1u : 0u) << e;
@@ -413,7 +455,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
             }
             if (ina) *reinterpret_cast<f32x4*>(im.out + pa * Cout + co) = ya;
             if (inb) *reinterpret_cast<f32x4*>(im.out + (pa + 1) * Cout + co) = yb;
-            if (im.bits_out) {
+            if (e_bits_out) {
                 const int pix = yy * 16 + 2 * p;
                 atomicOr(&WB[pix * 4 + w], na << sh);
                 atomicOr(&WB[(pix + 1) * 4 + w], nb << sh);
@@ -422,7 +464,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
         }
         const int py = (y0 + 2 * yp) >> 1, px = (x0 + 2 * p) >> 1;
         const bool inw = py < PH2 && px < PW2;
-        if (im.pool_out) {
+        if (e_pool_out) {
             // 2x2/2 max pool (+ the arg-max code the un-pooling loader of the backward pass reads: the window's FIRST maximum,
             // where it is positive - max_pool2d's backward and the ReLU mask of the pooled activation in one)
             f32x4 mx;
@@ -440,24 +482,24 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) cn[q] |= ((live && pos == q) ? 1u : 0u) << e;
             }
-            if (inw) *reinterpret_cast<f32x4*>(im.pool_out + ((size_t)py * PW2 + px) * Cout + co) = mx;
-            if (im.pcode_out) {
+            if (inw) *reinterpret_cast<f32x4*>(e_pool_out + ((size_t)py * PW2 + px) * Cout + co) = mx;
+            if (e_pcode_out) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) atomicOr(&PC[((yp * 8 + p) * 4 + w) * 4 + q], cn[q] << sh);
             }
         }
     }
-    if (im.bits_out || im.pcode_out) {
+    if (e_bits_out || e_pcode_out) {
         __syncthreads();          // the mask and code words are complete
-        if (im.bits_out) {
+        if (e_bits_out) {
             const int pix = tid >> 2, w2 = tid & 3;
             const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
-            if (gy < H && gx < W) im.bits_out[((size_t)gy * W + gx) * words + (n0 >> 5) + w2] = WB[tid];
+            if (gy < H && gx < W) e_bits_out[((size_t)gy * W + gx) * words + (n0 >> 5) + w2] = WB[tid];
         }
-        if (im.pcode_out) {
+        if (e_pcode_out) {
             const int pp = tid >> 4, w2 = (tid >> 2) & 3, q = tid & 3;
             const int qy = (y0 >> 1) + (pp >> 3), qx = (x0 >> 1) + (pp & 7);
-            if (qy < PH2 && qx < PW2) im.pcode_out[(((size_t)qy * PW2 + qx) * words + (n0 >> 5) + w2) * 4 + q] = PC[tid];
+            if (qy < PH2 && qx < PW2) e_pcode_out[(((size_t)qy * PW2 + qx) * words + (n0 >> 5) + w2) * 4 + q] = PC[tid];
         }
     }
     if (im.amax_out) {
@@ -473,10 +515,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
     WSTAMP_REAL(7);
 }
 
+namespace {
+template <bool UNPOOL, int MODE>
+hipError_t wino_attr() {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_batch_kernel<UNPOOL, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+}
+}  // namespace
+
 hipError_t conv_wino_init_device() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_batch_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wino_batch_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS);
+    hipError_t e = wino_attr<false, 0>();
+    if (e == hipSuccess) e = wino_attr<false, 1>();
+    if (e == hipSuccess) e = wino_attr<false, 2>();
+    if (e == hipSuccess) e = wino_attr<true, 0>();
+    if (e == hipSuccess) e = wino_attr<true, 2>();
+    return e;
 }
 
 bool conv_wino_eligible(const ConvBatch& b) {
@@ -499,8 +551,22 @@ hipError_t launch_conv_wino_batch(const ConvBatch& b0, hipStream_t stream) {
         tiles += b.img[i].tiles_x * ((b.img[i].H + W_TH - 1) / W_TH);
         b.img[i].tile_end = tiles;
     }
-    if (b.unpool) hipLaunchKernelGGL(conv_wino_batch_kernel<true>, dim3(tiles * (b.Cout / 128)), dim3(512), W_LDS, stream, b);
-    else hipLaunchKernelGGL(conv_wino_batch_kernel<false>, dim3(tiles * (b.Cout / 128)), dim3(512), W_LDS, stream, b);
+    // the epilogue form this launch fits (see the kernel's MODE)
+    bool fwd = b.relu && b.bias, bwd = !b.relu && !b.bias;
+    for (int i = 0; i < b.n; ++i) {
+        const ConvImage& im = b.img[i];
+        fwd = fwd && !im.addend && !im.bits_in;
+        bwd = bwd && !im.bits_out && !im.pool_out && !im.pcode_out;
+    }
+    const dim3 grid(tiles * (b.Cout / 128)), block(512);
+    if (b.unpool) {
+        if (bwd) hipLaunchKernelGGL((conv_wino_batch_kernel<true, 2>), grid, block, W_LDS, stream, b);
+        else hipLaunchKernelGGL((conv_wino_batch_kernel<true, 0>), grid, block, W_LDS, stream, b);
+    } else {
+        if (fwd) hipLaunchKernelGGL((conv_wino_batch_kernel<false, 1>), grid, block, W_LDS, stream, b);
+        else if (bwd) hipLaunchKernelGGL((conv_wino_batch_kernel<false, 2>), grid, block, W_LDS, stream, b);
+        else hipLaunchKernelGGL((conv_wino_batch_kernel<false, 0>), grid, block, W_LDS, stream, b);
+    }
     return hipGetLastError();
 }
 
