@@ -53,7 +53,7 @@ DTYPE = {"f32": "f32", "bf16x3": "f32 via bf16x3 split (6 bf16 MFMAs per product
          "f16x2": "f32 via f16x2 split (3 f16 MFMAs per product, f32 accumulate; the 14 large-channel conv launches of a closure as Winograd F(2,3) in that arithmetic)"}
 
 
-TRAFFIC_PROFILES = ("r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")
+TRAFFIC_PROFILES = ("r03_pmc_hbm_traffic.json", "r02_pmc_hbm_traffic.json", "r01_pmc_hbm_traffic.json")
 
 
 def committed_traffic_per_launch(kernel_prefix):
