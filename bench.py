@@ -79,6 +79,55 @@ def committed_traffic_per_launch(kernel_prefix):
     return None
 
 
+def measured_traffic(kernel_prefix, levels, timeout_s=150):
+    """HBM traffic of the dominant kernel measured in THIS run: two rocprofv3 counter passes (FETCH_SIZE, then WRITE_SIZE - they
+    do not fit one pass on gfx950) over a few closures of the same workload in a CHILD process (tools/pmc_run.py), after the
+    timed region; summed over the last closure's launches of the kernel and divided by their number.  FETCH_SIZE is doubled as
+    MI355X_MICROARCH.md prescribes for gfx950 (128-byte requests of 16-byte-per-lane streams are tallied at 64 B); the counter
+    sits at the L2's fabric side, so Infinity-Cache hits are included.  None when rocprofv3 is not there or a pass fails."""
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import summarize_pmc
+    except Exception:
+        return None
+    out = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+            env.pop(k, None)
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", d, "--",
+                   sys.executable, os.path.join(ROOT, "tools", "pmc_run.py"), str(levels), "2"]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+                if r.returncode != 0:
+                    return None
+                rows = summarize_pmc.rows_of(d)
+                vals, meta = summarize_pmc.per_dispatch(rows)
+                n = b = 0
+                for disp in summarize_pmc.last_closure(rows):
+                    name = summarize_pmc.short(meta[disp]["Kernel_Name"])
+                    if any(name.startswith(pfx) for pfx in kernel_prefix.split("|")):
+                        n += 1
+                        b += vals[disp].get(counter, 0.0) * 1024.0
+                out[counter] = (n, b)
+            except (SystemExit, Exception):
+                return None
+    (nf, fb), (nw, wb) = out["FETCH_SIZE"], out["WRITE_SIZE"]
+    if not nf or nf != nw:
+        return None
+    return {"gb_per_launch": (2.0 * fb + wb) / nf / 1e9, "fetch_gb_corrected": 2.0 * fb / 1e9, "write_gb": wb / 1e9, "launches": nf,
+            "what": "HBM (L2 fabric side) GB per launch of the dominant kernel over one closure of this workload: rocprofv3 --pmc "
+                    "FETCH_SIZE (x2, gfx950) and --pmc WRITE_SIZE, separate passes in a child process of this run"}
+
+
 class GpuSampler:
     """Shader clock (and board power) of one GPU sampled from sysfs every 50 ms on a thread: what the sustained figure is
     quoted with.  The conv kernel is power/clock bound, so a rate is only meaningful with its clock."""
@@ -367,6 +416,7 @@ def main():
     ap.add_argument("--sustained-seconds", type=float, default=5.0)
     ap.add_argument("--cpu-closures", type=int, default=2)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 counter passes behind roofline.traffic (~40 s)")
     ap.add_argument("--time-all-kernels", action="store_true", help="event pairs around every launch (slower)")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL over xGMI) or gloo (rehearsals)")
     ap.add_argument("--comm", default="c-abi", choices=["c-abi", "torch"],
@@ -616,6 +666,13 @@ def main():
             wg["what"] = ("the same job with nst_options.h2_winograd = 0: all 24 conv launches as direct convolutions "
                           "(3 f16 MFMAs per product everywhere)")
             out["direct_convolution"] = wg
+        if extras and "roofline" in out and not args.no_traffic and eng.conv_mode() == "f16x2":
+            # roofline.traffic: measured, not replayed - two counter passes in a child process (this process keeps its engines)
+            tr = measured_traffic("conv_h2_batch|conv_wino", args.levels)
+            if tr is not None:
+                out["roofline"]["traffic"] = tr["gb_per_launch"]
+                out["roofline"]["traffic_unit"] = "GB per launch"
+                out["roofline"]["traffic_detail"] = tr
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(job_host, cfg, args.cpu_closures)
         print(json.dumps(out), flush=True)

@@ -279,10 +279,8 @@ def test_closure_execution_modes_agree(eng, vgg_weights, opts):
     try:
         assert other.conv_mode() == opts.get("conv_mode", "f16x2")
         _setup(other, c, s)
-        # (per-term comparisons for the arithmetic modes; the schedules of the default arithmetic share its kernels'
-        # loss-term code and are held on the weighted sum and the TV term, whose signs are taken per schedule)
-        closure_vs_oracle_under_equal_decisions(other, xt, tg, vgg_weights, f"mode {opts}",
-                                                terms=TERMS if "conv_mode" in opts else (TERMS[0], TERMS[3]))
+        # (the weighted sum and every loss term alone, for the arithmetic modes and for the schedules alike)
+        closure_vs_oracle_under_equal_decisions(other, xt, tg, vgg_weights, f"mode {opts}", terms=TERMS)
         g0, l0 = eng.closure(x, CW, SW, TVW)
         g1 = l1 = None
         for _ in range(3 if opts.get("use_graph") else 1):     # same buffers again: captured on the 2nd call, replayed on the 3rd
