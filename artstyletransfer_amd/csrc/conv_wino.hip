@@ -77,6 +77,15 @@ __device__ __forceinline__ void cut2x4(const f32x4 v, const float s, u32x2& hi, 
     lo = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
 }
 
+// OR over the 8 lanes of an aligned 8-lane group (every lane gets the result): two quad permutes and a half-row mirror on
+// the DPP path - no LDS traffic, where eight lanes' atomicOr into one LDS word serialised.
+__device__ __forceinline__ unsigned or8(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);     // row_half_mirror: lane i <- lane 7 - i
+    return v;
+}
+
 __device__ __forceinline__ int xcd_order(const int b, const int grid) {
     const int x = b & 7, k = b >> 3;
     const int q = grid >> 3, r = grid & 7;
@@ -411,8 +420,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
                 const int m = (r & 3) + 8 * (r >> 2) + 4 * half;      // row of the 32-row tile
                 E[(xi * 64 + mt * 32 + m) * 128 + wn * 64 + nt * 32 + l31] = fmaf(accx[mt][nt][r], LO_DOWN, accm[mt][nt][r]) * inv;
             }
-    if (e_bits_out) WB[tid] = 0u;
-    if (e_pcode_out) PC[tid] = 0u;
     __syncthreads();
     WSTAMP(3);
     for (int pass = 0; pass < 2; ++pass) {      // the two 64-channel halves of the tile, one after the other per thread
@@ -457,8 +464,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
             if (inb) *reinterpret_cast<f32x4*>(im.out + (pa + 1) * Cout + co) = yb;
             if (e_bits_out) {
                 const int pix = yy * 16 + 2 * p;
-                atomicOr(&WB[pix * 4 + w], na << sh);
-                atomicOr(&WB[(pix + 1) * 4 + w], nb << sh);
+                // (the 8 threads cq & 7 = 0..7 hold the 8 nibbles of one 32-channel word)
+                const unsigned wa = or8(na << sh), wb = or8(nb << sh);
+                if ((cq & 7) == 0) { WB[pix * 4 + w] = wa; WB[(pix + 1) * 4 + w] = wb; }
             }
             win[k][0] = ya; win[k][1] = yb;
         }
@@ -485,7 +493,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino_batch_kernel(ConvBatch b) {
             if (inw) *reinterpret_cast<f32x4*>(e_pool_out + ((size_t)py * PW2 + px) * Cout + co) = mx;
             if (e_pcode_out) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) atomicOr(&PC[((yp * 8 + p) * 4 + w) * 4 + q], cn[q] << sh);
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned wq = or8(cn[q] << sh);
+                    if ((cq & 7) == 0) PC[((yp * 8 + p) * 4 + w) * 4 + q] = wq;
+                }
             }
         }
     }

@@ -133,8 +133,12 @@ def test_config3_product_generator_end_to_end(vgg_weights, job, golden):
 def test_config3_lbfgs_vs_reference_and_its_landing_points_taken_apart(eng, vgg_weights, job, golden):
     """The headline job under L-BFGS as the reference constructs it, from the reference's own start image, 24 closures."""
     c_lv, s_lv, init = job
+    # (from this start image every run rejects the second step - its curvature pair is rounding noise, measured in round 3:
+    # profiles/r03_parity_measurements.txt - so the oracle-optimiser block, which has only that decision to compare here, is
+    # left to the round-2 start image of tests/test_hip_optim.py, where the second step is accepted)
     lbfgs_vs_reference_taken_apart(eng, vgg_weights, c_lv, s_lv, cpu_ref.prepare_img(init), golden("job_lbfgs24_1024x1536_L2"), 24,
-                                   "config 3 (lbfgs as shipped, 24 closures @L=2, the reference's own start image)")
+                                   "config 3 (lbfgs as shipped, 24 closures @L=2, the reference's own start image)",
+                                   oracle_optimiser=False)
 
 
 def test_config3_lbfgs_line_search_vs_reference(eng, job, golden):

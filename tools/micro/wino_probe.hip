@@ -25,6 +25,7 @@ int main(int argc, char** argv) {
     const int Cin = argc > 1 ? atoi(argv[1]) : 256, Cout = argc > 2 ? atoi(argv[2]) : 256;
     const int H0 = argc > 3 ? atoi(argv[3]) : 256, W0 = argc > 4 ? atoi(argv[4]) : 384;
     const int unpool = argc > 5 ? atoi(argv[5]) : 0, relu = argc > 6 ? atoi(argv[6]) : 1;
+    const int nobits = argc > 7 ? atoi(argv[7]) : 0, pool = argc > 8 ? atoi(argv[8]) : 0;      // experiment switches: no mask words / pooled output too
     const int nimg = 3;
     CK(nst::conv_wino_init_device());
     std::mt19937 rng(1);
@@ -54,7 +55,11 @@ int main(int argc, char** argv) {
         std::vector<unsigned> amv(64, 0x40a00000u);      // 5.0f
         CK(hipMemcpy(am, amv.data(), 256, hipMemcpyHostToDevice)); im.amax_in = am;
         unsigned* ao; CK(hipMalloc(&ao, 64 * 4)); CK(hipMemset(ao, 0, 256)); im.amax_out = ao;
-        if (relu) { unsigned* bo; CK(hipMalloc(&bo, px_out * (Cout / 32) * 4)); im.bits_out = bo; }
+        if (relu && !nobits) { unsigned* bo; CK(hipMalloc(&bo, px_out * (Cout / 32) * 4)); im.bits_out = bo; }
+        if (relu && pool) {
+            float* po; CK(hipMalloc(&po, (px_out / 4 + 1) * Cout * 4)); im.pool_out = po;
+            unsigned* pc; CK(hipMalloc(&pc, (px_out / 4 + 1) * (Cout / 32) * 16)); im.pcode_out = pc;
+        }
         else { unsigned* bi; CK(hipMalloc(&bi, px_out * (Cout / 32) * 4)); CK(hipMemset(bi, 0xFF, px_out * (Cout / 32) * 4)); im.bits_in = bi; }
         if (unpool) {
             std::vector<unsigned> code(px_in * (Cin / 32) * 4);
