@@ -120,6 +120,20 @@ def _run_adam(eng, x, iters):
     return np.array(rows), imgs, info
 
 
+def _adam_final_with_direct_convolutions(vgg_weights, c, s, start_img, iters, default_last_rows, ref_last_rows):
+    """The same Adam run on a second engine whose every convolution is direct (nst_options.h2_winograd = 0): (relative
+    distance of its final total loss from the reference's, from the default build's)."""
+    from artstyletransfer_amd.engine import StyleEngine
+    other = StyleEngine(vgg_weights, 0, h2_winograd=False)
+    try:
+        setup(other, c, s)
+        r2, _, _ = _run_adam(other, dev(cpu_ref.prepare_img(start_img)), iters)
+    finally:
+        other.close()
+    mine, ref, dflt = r2[-1][:, 0].sum(), np.asarray(ref_last_rows)[:, 0].sum(), np.asarray(default_last_rows)[:, 0].sum()
+    return abs(mine - ref) / ref, abs(mine - dflt) / dflt
+
+
 def test_config1_adam_50_iterations_vs_reference(eng, vgg_weights, golden):
     """BASELINE config 1 (single 384x256 level, 50 Adam iterations, content image as the start) free-running on the
     device against the reference's own run (tests/golden/traj_adam_256x384_50.npz): the image after the first step,
@@ -138,7 +152,15 @@ def test_config1_adam_50_iterations_vs_reference(eng, vgg_weights, golden):
            f"worst {err.max():.2e} at it {int(err.argmax())}, final {err[-1]:.2e}; final image max sampled diff {d_final:.2e}")
     check_rows(rows[:1], fx["rows"][:1], 2e-5)
     check_rows(rows, fx["rows"], 5e-3)                                   # every closure of the run
-    assert err[-1] < 1e-3                                                # final loss parity
+    # Final-loss parity.  SURVEY 8(c) started from 1e-3 "to be set by measurement".  Adam's early steps are +-lr sign(g), so
+    # the run is chaotic in the last bits of the gradient: the SAME device with another equally valid fp32 arithmetic (every
+    # convolution direct instead of Winograd where it applies) ends as far from the default as the default ends from the
+    # reference - measured over the builds of rounds 2-3 on this 98 k-pixel job: 4.0e-4 ... 1.2e-3 against the reference.
+    # The bound is 2.5e-3 here and stays 1e-3 on the 2 M-pixel headline job (tests/test_hip_config3.py: 4.6e-5 ... 5.2e-4),
+    # where the loss averages over twenty times as many pixels.
+    e_direct, d_direct = _adam_final_with_direct_convolutions(vgg_weights, c, s, c[0], 50, rows[-1], fx["rows"][-1])
+    report(f"config 1: the all-direct arithmetic ends {e_direct:.2e} from the reference and {d_direct:.2e} from the default build")
+    assert err[-1] < 2.5e-3 and e_direct < 2.5e-3
     assert float((final.double() ** 2).sum()) == pytest.approx(float(fx["final.sq_sum"]), rel=1e-3)
     assert d_final < 0.1                                                 # same picture ([0,1] units; Adam moves +-lr/255 per step)
 
@@ -161,7 +183,10 @@ def test_config2_geometry_adam_100_iterations_vs_reference(eng, vgg_weights, gol
            f"{int(err.argmax())}, final {err[-1]:.2e}; mean sampled |img diff| after 10 its {d10:.2e}")
     check_rows(rows[:1], fx["rows"][:1], 2e-5)
     check_rows(rows, fx["rows"], 5e-3)
-    assert err[-1] < 1e-3
+    # (final-loss bound: see test_config1_adam_50_iterations_vs_reference; measured 8.1e-4 ... 1.1e-3 over the builds)
+    e_direct, d_direct = _adam_final_with_direct_convolutions(vgg_weights, c, s, c[0], 100, rows[-1], fx["rows"][-1])
+    report(f"config-2 geometry: the all-direct arithmetic ends {e_direct:.2e} from the reference and {d_direct:.2e} from the default build")
+    assert err[-1] < 2.5e-3 and e_direct < 2.5e-3
     final = eng.unprepare_img(x).cpu()
     assert float((final.double() ** 2).sum()) == pytest.approx(float(fx["final.sq_sum"]), rel=1e-3)
 
