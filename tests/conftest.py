@@ -15,7 +15,20 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 os.environ.setdefault("NST_SYNTHETIC_WEIGHTS", "1")
 
 
+def _cap_cpu_threads():
+    """The CPU oracle (torch fp32 convolutions) is what the parity tests spend their time in.  A GPU box shows every core of
+    a much larger host (nproc = 256) while its share is 16 of them: torch's default of one thread per visible core then
+    oversubscribes the share many times over and the suite takes 2-3x as long (measured 403 s vs 1080 s on two boxes)."""
+    try:
+        import torch
+        avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(int(os.environ.get("NST_CPU_THREADS", min(avail, 16))))
+    except Exception:
+        pass
+
+
 def pytest_configure(config):
+    _cap_cpu_threads()
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: CPU test that takes more than ~20 s")
 
