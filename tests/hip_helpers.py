@@ -410,9 +410,11 @@ def lbfgs_vs_reference_taken_apart(eng, vgg_weights, c_lv, s_lv, x_init, fx, clo
         # Rejected in the reference's run and here.  Where the first step is as short as it is from the reference's own
         # start image (y.s within two decades of torch's 1e-10 guard, |g1| / |y| ~ 3e3), the curvature pair is rounding
         # noise of two gradient evaluations and the two-loop recursion divides by it: the trial point's loss is a number of
-        # the reference's arithmetic on one host, not of the algorithm (measured: reference 1.96e6, the oracle under the
-        # device's decisions 73x that, the device 110x, the all-direct build 310x - every one of them far above f, so every
-        # run rejects the step and keeps the same image).  What is compared is that decision.
+        # one implementation's arithmetic, not of the algorithm (measured: reference 1.96e6, the oracle under the device's
+        # decisions 78x that, the device 110x, the all-direct build 310x - every one of them far above f, so every run
+        # rejects the step and keeps the same image; on the CPU alone the reference's fp32 y is 117 % away from the fp64 y
+        # of the same two images: tools/diag_first_pair_noise.py, profiles/r03_lbfgs_first_pair_noise.txt).  What is
+        # compared is that decision.
         runs = [(tot[3], tot[2]), (ref[3], ref[2]), (t2[3], t2[2])] + ([(o_tot[3], o_tot[2])] if o_tot is not None else [])
         for trial, kept in runs:
             assert trial > 2.0 * kept
