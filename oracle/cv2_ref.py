@@ -13,9 +13,14 @@ every one of them against an INDEPENDENT implementation of the same documented r
   cv2.getGaussianKernel          <->  scipy.signal.windows.gaussian, normalised
   cv2.GaussianBlur               <->  scipy.ndimage.correlate1d with that kernel, mode="mirror"
 
-Parity status of rows f-1 / f-2: pinned by independent implementation (not by the reference's own output, which needs
-cv2).  Only `tests/` may import this module; the product's host mirror is artstyletransfer_amd/host_image.py and the
-device kernels are artstyletransfer_amd/csrc/image_ops.hip - both are compared with this file.
+Parity status of rows f-1 / f-2 (round 3).  The four OPERATORS above: pinned by independent implementation (OpenCV itself
+cannot run here).  The reference's own job-driver LOGIC restated in the second half of this file (level_size, gaussian_mask,
+make_style_noise, noise_map, gradient_weight, initial_image): pinned by the reference itself - tests/golden/make_fixtures.py
+runs the reference's neural_style_transfer() with a cv2 stand-in whose four functions call the operators of THIS file, and
+tests/test_oracle_jobsetup.py holds these restatements to what the reference produced bit for bit (tests/golden/jobsetup.npz).
+Only `tests/` (and that fixture generator) may import this module; the product's host mirror is
+artstyletransfer_amd/host_image.py and the device kernels are artstyletransfer_amd/csrc/image_ops.hip - both are compared
+with this file and with the reference-made fixture.
 """
 from __future__ import annotations
 
