@@ -2,8 +2,9 @@
 initial image (reference: neural_style_transfer.py:211-226, :249-362, :396-439).
 
 The reference does this with OpenCV, which is absent offline; the OpenCV operators it calls are
-restated here from their documented semantics (no in-container oracle exists for them - parity at
-the cv2 boundary is unpinned):
+restated here from their documented semantics (pinned by independent implementations in
+tests/test_oracle_cv2.py; the driver logic around them by what the reference's own
+neural_style_transfer() produced, tests/test_oracle_jobsetup.py - see DESIGN.md section 2):
   cv2.resize(..., INTER_CUBIC)   bicubic, A = -0.75, half-pixel centres, replicate border, no antialias
                                  (the rule torch's bicubic follows: torch:include/ATen/native/UpSample.h:297-309)
   cv2.Sobel(ksize=5)             separable [-1,-2,0,2,1] x [1,4,6,4,1], BORDER_REFLECT_101
