@@ -4,6 +4,8 @@
 //
 // Forward: implicit GEMM with K = 27 (padded to 28) on v_mfma_f32_32x32x2_f32; the 28x64 weight
 // table lives in registers, the 3-plane halo patch in LDS.
+// Input gradient: conv1_1_dgrad_h2_kernel (two-piece fp16 arithmetic on v_mfma_f32_16x16x32_f16, the default) and
+// conv1_1_dgrad_kernel (fp32 on the VALU, for the paths that record no absmax).
 #include <hip/hip_runtime.h>
 
 #include "nst_kernels.h"
@@ -13,6 +15,9 @@ namespace nst {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 // Block tile: 16 x 16 pixels, 4 waves of 4 rows (two 32-pixel MFMA row tiles per wave).
@@ -188,8 +193,7 @@ hipError_t launch_conv1_1_fwd(const float* x, int H, int W, const float* wk, con
 }
 
 // Input gradient of conv1_1: gx[c][y][x] = sum_{tap, co} g[y+dy-1][x+dx-1][co] * wd[tap][co][c]
-// (wd holds the tap-flipped weights).  N = 3 output channels is no MFMA shape (a 32-wide tile would
-// waste 29/32 of the matrix pipe), so this runs on the VALU: one pixel per lane, three accumulators,
+// (wd holds the tap-flipped weights).  The fp32 form, on the VALU: one pixel per lane, three accumulators,
 // the 64-channel gradient of the 18x18 halo patch staged through LDS in two 32-channel slices
 // (144-B rows: conflict-light ds_read_b128), weights wave-uniform through the scalar path.
 namespace {
@@ -263,9 +267,176 @@ __global__ __launch_bounds__(256) void conv1_1_dgrad_kernel(const float* __restr
     }
 }
 
-hipError_t launch_conv1_1_dgrad(const float* g, int H, int W, const float* wd, float* gx, hipStream_t stream) {
+// The same sum on the matrix pipe, in the two-piece fp16 arithmetic of conv_h2.hip (every fp32 operand = hi + 2^-11 lo in
+// fp16 under a power-of-two scale; main and cross products in separate fp32 accumulators).  N = 3 wastes 13/16 of a
+// 16-wide tile, so the three tap ROWS are made output columns as well: with
+//     P[ky][c][t][x] = sum_{kx, co} g[t][x + kx - 1][co] * wd[ky*3 + kx][co][c]        (t = a row of the halo patch)
+// the gradient is gx[c][y][x] = P[0][c][y-1][x] + P[1][c][y][x] + P[2][c][y+1][x]: one GEMM with M = the pixels of a patch
+// row, N = (ky, c) = 9 of 16 columns, K = (kx, co) = 192, and three accumulators of neighbouring patch rows added across
+// lanes at the end.  v_mfma_f32_16x16x32_f16: lane (l15, kg) holds A[pixel l15][k = 8 kg + j], B[k = 8 kg + j][column l15],
+// D[pixel 4 kg + i][column l15].  A wave owns four image rows = six patch rows (two recomputed per wave: 54 MFMAs per
+// 32-channel slice where the VALU form spends 288 fma + 288 pk_fma per lane).  The 12 weight fragments (3 kx x 2 slices
+// x 2 pieces = 48 registers) stay in registers for the whole kernel; the patch is cut into pieces on its way into LDS
+// (144-B pixel rows: 16 consecutive pixels on 16 distinct 16-B slots).  The gradient's scale comes from the absmax slots the
+// producing launch recorded (conv_h2.hip epilogue), the weights' from their own maximum.
+namespace {
+constexpr int G_P = D_T + 2;
+constexpr int G_KC = 32;
+constexpr int G_PIECEB = G_KC * 2;
+constexpr int G_ROWB = 2 * G_PIECEB + 16;
+constexpr int G_UNITS = G_P * G_P * (G_KC / 4);
+constexpr int G_PER_T = (G_UNITS + 255) / 256;
+constexpr float G_LO_UP = 2048.f, G_LO_DOWN = 1.f / 2048.f;
+
+// power-of-two scale bringing a tensor of largest magnitude (bit pattern) m into [2^14, 2^15), and its inverse
+__device__ __forceinline__ void pow2_scale(const unsigned m, float& s, float& inv) {
+    int e = (int)((m >> 23) & 0xFFu);
+    e = e < 32 ? 32 : (e > 250 ? 250 : e);
+    s = __uint_as_float((unsigned)(268 - e) << 23);
+    inv = __uint_as_float((unsigned)(e - 14) << 23);
+}
+__device__ __forceinline__ unsigned wave_max(unsigned m) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned o = (unsigned)__shfl_xor((int)m, off);
+        m = o > m ? o : m;
+    }
+    return m;
+}
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void conv1_1_dgrad_h2_kernel(const float* __restrict__ g, int H, int W,
+                                                                  const float* __restrict__ wd,
+                                                                  const unsigned* __restrict__ amax_g, float* __restrict__ gx,
+                                                                  int ntiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char patch[G_P * G_P * G_ROWB];
+    __shared__ unsigned wmax[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, kg = lane >> 4;
+    const int tiles_x = (W + D_T - 1) / D_T;
+
+    // a 32-channel slice of a tile's halo patch: global -> registers here, registers -> LDS (cut into pieces) at the top
+    // of the slice's turn; the fetch of the NEXT slice (of this tile or of the workgroup's next one) is always in flight
+    // under the MFMAs of the current one
+    f32x4 stage[G_PER_T];
+    auto fetch = [&](const int tile, const int chunk) {
+        const int y0 = (tile / tiles_x) * D_T, x0 = (tile % tiles_x) * D_T;
+#pragma unroll
+        for (int i = 0; i < G_PER_T; ++i) {
+            const int u = tid + i * 256;
+            const int pix = u / (G_KC / 4), q = u % (G_KC / 4);
+            const int gy = y0 - 1 + pix / G_P, gxx = x0 - 1 + pix % G_P;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (u < G_UNITS && tile < ntiles && gy >= 0 && gy < H && gxx >= 0 && gxx < W)
+                v = *reinterpret_cast<const f32x4*>(g + ((size_t)gy * W + gxx) * 64 + chunk * G_KC + q * 4);
+            stage[i] = v;
+        }
+    };
+    fetch(blockIdx.x, 0);
+
+    // scales: the gradient's from its recorded absmax, the weights' from their own
+    float sg, inv_g, sw, inv_w;
+    pow2_scale(wave_max(amax_g[lane]), sg, inv_g);
+    {
+        unsigned m = 0;
+        for (int i = tid; i < 9 * 64 * 4; i += 256) {
+            const unsigned b = __float_as_uint(wd[i]) & 0x7FFFFFFFu;
+            m = b > m ? b : m;
+        }
+        m = wave_max(m);
+        if (lane == 0) wmax[wave] = m;
+        __syncthreads();
+        unsigned a = wmax[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i) a = wmax[i] > a ? wmax[i] : a;
+        pow2_scale(a, sw, inv_w);
+    }
+    // weight fragments, once per workgroup: column l15 = ky*3 + c (columns 9..15 are zero), k = (kx, co = 32 slice + 8 kg + j)
+    f16x8 bh[3][2], bl[3][2];
+    {
+        const bool valid = l15 < 9;
+        const int ky = valid ? l15 / 3 : 0, c = valid ? l15 % 3 : 0;
+        const float swz = valid ? sw : 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int co = sl * G_KC + kg * 8 + j;
+                    const float v = wd[((ky * 3 + kx) * 64 + co) * 4 + c] * swz;       // unconditional: the 48 loads overlap
+                    const _Float16 hi = (_Float16)v;
+                    bh[kx][sl][j] = hi;
+                    bl[kx][sl][j] = (_Float16)((v - (float)hi) * G_LO_UP);
+                }
+    }
+    const float inv = inv_g * inv_w;
+    const size_t HW = (size_t)H * W;
+    const unsigned char* abase = patch + ((wave * 4) * G_P + l15) * G_ROWB + kg * 16;
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        f32x4 am[6], ax[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) { am[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ax[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int chunk = 0; chunk < 64 / G_KC; ++chunk) {
+            __syncthreads();                 // the previous slice's fragments have been read
+#pragma unroll
+            for (int i = 0; i < G_PER_T; ++i) {
+                const int u = tid + i * 256;
+                if (u < G_UNITS) {
+                    const f32x4 v = stage[i] * sg;
+                    const f32x2 x01 = {v[0], v[1]}, x23 = {v[2], v[3]};
+                    const f16x2 h01 = __builtin_convertvector(x01, f16x2), h23 = __builtin_convertvector(x23, f16x2);
+                    const f32x2 r01 = (x01 - __builtin_convertvector(h01, f32x2)) * G_LO_UP;
+                    const f32x2 r23 = (x23 - __builtin_convertvector(h23, f32x2)) * G_LO_UP;
+                    const f16x2 l01 = __builtin_convertvector(r01, f16x2), l23 = __builtin_convertvector(r23, f16x2);
+                    unsigned char* row = patch + (u / (G_KC / 4)) * G_ROWB + (u % (G_KC / 4)) * 8;
+                    *reinterpret_cast<u32x2*>(row) = u32x2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+                    *reinterpret_cast<u32x2*>(row + G_PIECEB) = u32x2{__builtin_bit_cast(unsigned, l01), __builtin_bit_cast(unsigned, l23)};
+                }
+            }
+            __syncthreads();
+            if (chunk == 0) fetch(tile, 1);          // the next slice (of this tile, or of the workgroup's next tile) is
+            else fetch(tile + gridDim.x, 0);         // in flight under this slice's MFMAs
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const unsigned char* a = abase + (t * G_P + kx) * G_ROWB;
+                    const f16x8 ah = *reinterpret_cast<const f16x8*>(a);
+                    const f16x8 al = *reinterpret_cast<const f16x8*>(a + G_PIECEB);
+                    ax[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[kx][chunk], ax[t], 0, 0, 0);
+                    am[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[kx][chunk], am[t], 0, 0, 0);
+                    ax[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[kx][chunk], ax[t], 0, 0, 0);
+                }
+        }
+        // row r of the wave: P[0] of patch row r (column c) + P[1] of patch row r + 1 (column 3 + c) + P[2] of r + 2 (6 + c)
+        const int y0 = (tile / tiles_x) * D_T, x0 = (tile % tiles_x) * D_T;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = y0 + wave * 4 + r;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v0 = am[r][i] + ax[r][i] * G_LO_DOWN;
+                const float v1 = am[r + 1][i] + ax[r + 1][i] * G_LO_DOWN;
+                const float v2 = am[r + 2][i] + ax[r + 2][i] * G_LO_DOWN;
+                const float s = (v0 + __shfl(v1, lane + 3) + __shfl(v2, lane + 6)) * inv;
+                const int x = x0 + kg * 4 + i;
+                if (l15 < 3 && y < H && x < W) gx[l15 * HW + (size_t)y * W + x] = s;
+            }
+        }
+    }
+}
+
+hipError_t launch_conv1_1_dgrad(const float* g, int H, int W, const float* wd, const unsigned* amax_g, float* gx,
+                                hipStream_t stream) {
     const int blocks = ((H + D_T - 1) / D_T) * ((W + D_T - 1) / D_T);
-    hipLaunchKernelGGL(conv1_1_dgrad_kernel, dim3(blocks), dim3(256), 0, stream, g, H, W, wd, gx);
+    if (amax_g)     // two workgroups per CU, each walking tiles b, b + grid, ...: scales and weight fragments once per workgroup
+        hipLaunchKernelGGL(conv1_1_dgrad_h2_kernel, dim3(blocks < 512 ? blocks : 512), dim3(256), 0, stream, g, H, W, wd, amax_g,
+                           gx, blocks);
+    else
+        hipLaunchKernelGGL(conv1_1_dgrad_kernel, dim3(blocks), dim3(256), 0, stream, g, H, W, wd, gx);
     return hipGetLastError();
 }
 

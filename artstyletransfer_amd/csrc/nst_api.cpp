@@ -574,7 +574,7 @@ int backward(nst_ctx* ctx, ActSet& a, const Inject* inj, const ContentJob* cj, f
     }
     {
         Timer t(ctx, s, K_CONV1, conv_flops(h, w, 64, 3, 9));
-        HIPCHK(ctx, launch_conv1_1_dgrad(cur, h, w, ctx->w11d, gx, s));
+        HIPCHK(ctx, launch_conv1_1_dgrad(cur, h, w, ctx->w11d, h2 ? amax_grad(a, 0) : nullptr, gx, s));
     }
     return NST_OK;
 }
@@ -832,7 +832,7 @@ int batched_backward(nst_ctx* ctx, const float* const* xi, float* const* gi, con
         LevelWs& L = ctx->lv[lv[k]];
         {
             Timer t(ctx, s, K_CONV1, conv_flops(L.h, L.w, 64, 3, 9));
-            HIPCHK(ctx, launch_conv1_1_dgrad(cur[k], L.h, L.w, ctx->w11d, gi[lv[k]], s));
+            HIPCHK(ctx, launch_conv1_1_dgrad(cur[k], L.h, L.w, ctx->w11d, h2 ? amax_grad(L.acts, 0) : nullptr, gi[lv[k]], s));
         }
         Timer t(ctx, s, K_OTHER, 0);
         if (win)

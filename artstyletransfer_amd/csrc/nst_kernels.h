@@ -132,7 +132,9 @@ hipError_t launch_conv1_1_fwd(const float* x, int H, int W, const float* wk, con
                               unsigned* bits_out, unsigned* amax_out, hipStream_t stream);
 // g: [H][W][64] gradient w.r.t. the pre-ReLU conv1_1 output; wd: [9][64][4] flipped taps
 // (wd[t][co][c] = W[co][c][2-ky][2-kx], c = 3 unused 0); gx planar (3,H,W), overwritten.
-hipError_t launch_conv1_1_dgrad(const float* g, int H, int W, const float* wd, float* gx, hipStream_t stream);
+// amax_g: the absmax slots of g (the matrix-pipe form), or null (fp32 on the VALU)
+hipError_t launch_conv1_1_dgrad(const float* g, int H, int W, const float* wd, const unsigned* amax_g, float* gx,
+                                hipStream_t stream);
 
 // pixel_ops.hip ---------------------------------------------------------------------------------
 // 2x2/2 max pool (floor) over NHWC, C % 4 == 0
