@@ -319,8 +319,23 @@ __global__ __launch_bounds__(256, 2) void conv1_1_dgrad_h2_kernel(const float* _
     // of the slice's turn; the fetch of the NEXT slice (of this tile or of the workgroup's next one) is always in flight
     // under the MFMAs of the current one
     f32x4 stage[G_PER_T];
+    // (the staging is VALU work beside the MFMAs: a tile whose halo patch lies inside the image - all but the rim - takes
+    // its 11 addresses from a per-lane offset table instead of deriving and bounds-testing each)
+    unsigned off[G_PER_T];
+#pragma unroll
+    for (int i = 0; i < G_PER_T; ++i) {
+        const int u = tid + i * 256;
+        const int pix = u < G_UNITS ? u / (G_KC / 4) : 0, q = u % (G_KC / 4);
+        off[i] = (unsigned)(((pix / G_P) * W + pix % G_P) * 64 + q * 4);
+    }
     auto fetch = [&](const int tile, const int chunk) {
         const int y0 = (tile / tiles_x) * D_T, x0 = (tile % tiles_x) * D_T;
+        if (tile < ntiles && y0 >= 1 && x0 >= 1 && y0 + D_T + 1 <= H && x0 + D_T + 1 <= W) {       // workgroup-uniform
+            const float* base = g + ((size_t)(y0 - 1) * W + (x0 - 1)) * 64 + chunk * G_KC;
+#pragma unroll
+            for (int i = 0; i < G_PER_T; ++i) stage[i] = *reinterpret_cast<const f32x4*>(base + off[i]);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < G_PER_T; ++i) {
             const int u = tid + i * 256;
