@@ -43,6 +43,9 @@ namespace {
 #ifndef NST_H2_DEEP_WEIGHT_PREFETCH
 #define NST_H2_DEEP_WEIGHT_PREFETCH 1
 #endif
+#ifndef NST_H2_WEIGHT_SETS4
+#define NST_H2_WEIGHT_SETS4 1
+#endif
 // Timing-only builds (tools/ablate_conv.sh; never shipped): a set bit gives one stream of the kernel a buffer descriptor
 // with zero records, so the range check drops its loads / stores while the instruction stream, the waits and the
 // barriers stay - the launch then shows what that stream's memory traffic costs.  bit 0: the patch loads of the main
@@ -171,6 +174,10 @@ __device__ __forceinline__ void conv_h2_body(const Tiles& tiles, const int slot_
     // (KC == 16 shapes: a second weight staging set, see the main K loop)
     constexpr bool DEEPB = (KC == 16) && NST_H2_DEEP_WEIGHT_PREFETCH;
     u32x4 rb2[DEEPB ? C::B_PER_T : 1];
+    // (one 16-byte unit per lane and slice - the 64-channel shape: FOUR sets, a slice is requested four stages before it
+    // goes to LDS; the sets are handed down from stage to stage)
+    constexpr bool DEEPB4 = DEEPB && C::B_PER_T == 1 && NST_H2_WEIGHT_SETS4;
+    u32x4 rb3[DEEPB4 ? C::B_PER_T : 1], rb4[DEEPB4 ? C::B_PER_T : 1];
 
     ConvParams p;
     int sp = 0, ct = 0;
@@ -565,6 +572,7 @@ __device__ __forceinline__ void conv_h2_body(const Tiles& tiles, const int slot_
             load_b(r1, 0, 1, tid, n0);
             load_b(rb, 0, 2, tid, n0);
             if constexpr (DEEPB) load_b(rb2, 0, 3, tid, n0);
+            if constexpr (DEEPB4) { load_b(rb3, 0, 4, tid, n0); load_b(rb4, 0, 5, tid, n0); }
             __syncthreads();          // the previous source is done with the LDS buffers
             store_a(ldsA, sa, ra, 0, C::A_PER_T, tid, UNPOOL ? rc : nullptr, bit0_of(0));
             store_b(ldsB, r0, tid);
@@ -610,7 +618,13 @@ __device__ __forceinline__ void conv_h2_body(const Tiles& tiles, const int slot_
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 // top of stage g = 9 c + t: slice g+2 to LDS, slice g+3 on its way
-                if constexpr (DEEPB) {
+                if constexpr (DEEPB4) {
+                    store_b(ldsB + ((t + 2) % 3) * C::B_BYTES, rb, to);
+#pragma unroll
+                    for (int i = 0; i < C::B_PER_T; ++i) { rb[i] = rb2[i]; rb2[i] = rb3[i]; rb3[i] = rb4[i]; }
+                    if (t + 6 < 9) load_b(rb4, c, t + 6, to, n0);
+                    else load_b(rb4, cn, t + 6 - 9, to, ahead.n0);
+                } else if constexpr (DEEPB) {
                     // 16-channel chunks: a stage is 12 MFMAs (~400 cycles, ~800 with the other workgroup's wave on the SIMD) -
                     // shorter than an L2 round trip, so a slice loaded ONE stage ahead arrives late and every stage
                     // waits for it.  Two register sets alternate: slice g+2 goes to LDS from the set loaded two stages

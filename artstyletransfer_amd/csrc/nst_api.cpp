@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -171,10 +173,43 @@ int fail(nst_ctx* ctx, int code, const std::string& msg) {
         if (_r != NST_OK) return _r; \
     } while (0)
 
+// Debugging aid (tools/check_uninit_reads.py): NST_POISON_ALLOC=all | <first>-<last> fills the allocations with those
+// sequence numbers with 0xFF bytes (NaN as floats, all-ones as masks), so that a kernel which reads memory nobody wrote -
+// harmless on a fresh process, whose pages arrive zeroed, and wrong once the allocator recycles another context's blocks -
+// shows in the results of a single job.
+void poison_if_asked(void* p, size_t bytes) {
+    static const char* spec = getenv("NST_POISON_ALLOC");
+    static std::atomic<long> seq{0};
+    if (!spec || !*spec) return;
+    const long k = seq++;
+    long lo = 0, hi = -1;
+    if (strcmp(spec, "all") == 0) hi = LONG_MAX;
+    else if (sscanf(spec, "%ld-%ld", &lo, &hi) != 2) return;
+    if (k >= lo && k <= hi) { (void)hipMemset(p, 0xFF, bytes); (void)hipStreamSynchronize(nullptr); }
+    if (getenv("NST_POISON_TRACE")) fprintf(stderr, "nst alloc #%ld: %zu bytes%s\n", k, bytes, (k >= lo && k <= hi) ? " (poisoned)" : "");
+}
+
+}  // namespace
+// hipMemset on device memory is enqueued on the NULL stream and returns before it has run: with another context's work
+// queued there (two jobs per GPU is the scheduler's default) it lands AFTER the first kernels of this context, which run on
+// the caller's non-blocking stream - and wipes what they wrote (absmax records -> a zero scale -> NaN targets; Adam
+// moments; the packed loss rows).  Set-up-time zero fills therefore run on a stream of their own and are waited for:
+// nothing of a context rides on the null stream.
+extern "C" int nst_internal_zero_now(void* p, size_t bytes) {
+    hipStream_t zs = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&zs, hipStreamNonBlocking);
+    if (e != hipSuccess) return 1;
+    e = hipMemsetAsync(p, 0, bytes, zs);
+    if (e == hipSuccess) e = hipStreamSynchronize(zs);
+    (void)hipStreamDestroy(zs);
+    return e == hipSuccess ? 0 : 1;
+}
+namespace {
 int dev_alloc(nst_ctx* ctx, void** p, size_t bytes) {
     if (bytes == 0) bytes = 16;
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) return fail(ctx, NST_E_NOMEM, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    poison_if_asked(*p, bytes);
     ctx->bytes += bytes;
     return NST_OK;
 }
@@ -221,7 +256,7 @@ int alloc_acts(nst_ctx* ctx, ActSet& a, int h, int w) {
     }
     NSTCHK(dev_alloc_t(ctx, &a.amax, (size_t)AMAX_IDS * NST_AMAX_SLOTS));
     a.bytes += (size_t)AMAX_IDS * NST_AMAX_SLOTS * 4;
-    if (hipMemset(a.amax, 0, (size_t)AMAX_IDS * NST_AMAX_SLOTS * 4) != hipSuccess) return fail(ctx, NST_E_HIP, "hipMemset failed");
+    if (nst_internal_zero_now(a.amax, (size_t)AMAX_IDS * NST_AMAX_SLOTS * 4)) return fail(ctx, NST_E_HIP, "hipMemset failed");
     a.splitk_floats = need;
     if (need) {
         NSTCHK(dev_alloc_t(ctx, &a.splitk, need));
@@ -1772,6 +1807,7 @@ int nst_internal_device(const nst_ctx* ctx) { return ctx ? ctx->device : 0; }
 int nst_internal_levels(const nst_ctx* ctx) { return ctx ? ctx->levels : 0; }
 size_t nst_internal_pixels(const nst_ctx* ctx) { return (ctx && ctx->levels > 0) ? (size_t)ctx->lv[0].h * ctx->lv[0].w : 0; }
 int nst_internal_fail(nst_ctx* ctx, int code, const char* msg) { return fail(ctx, code, msg ? msg : ""); }
+void nst_internal_poison(void* p, size_t bytes) { poison_if_asked(p, bytes); }
 int nst_internal_lbfgs_gram(const nst_ctx* ctx) { return ctx ? ctx->lbfgs_gram : 1; }
 void nst_internal_mark(nst_ctx* ctx, void* stream) { mark(ctx, static_cast<hipStream_t>(stream)); }
 

@@ -23,6 +23,8 @@ extern "C" int nst_internal_device(const nst_ctx* ctx);
 extern "C" int nst_internal_levels(const nst_ctx* ctx);
 extern "C" size_t nst_internal_pixels(const nst_ctx* ctx);
 extern "C" int nst_internal_fail(nst_ctx* ctx, int code, const char* msg);
+extern "C" void nst_internal_poison(void* p, size_t bytes);
+extern "C" int nst_internal_zero_now(void* p, size_t bytes);      // a zero fill that has RUN when it returns (nst_api.cpp)
 extern "C" int nst_internal_lbfgs_gram(const nst_ctx* ctx);
 extern "C" void nst_internal_mark(nst_ctx* ctx, void* stream);
 
@@ -100,6 +102,7 @@ namespace {
 int oalloc(nst_opt* o, float** p, size_t n) {
     hipError_t e = hipMalloc(reinterpret_cast<void**>(p), n * sizeof(float));
     if (e != hipSuccess) return nst_internal_fail(o->ctx, NST_E_NOMEM, "hipMalloc failed in optimiser");
+    nst_internal_poison(*p, n * sizeof(float));
     return NST_OK;
 }
 
@@ -469,7 +472,7 @@ int nst_opt_create(nst_ctx* ctx, int kind, float lr_start, int lbfgs_max_eval, n
     const size_t n_pad = (o->n + 63) & ~(size_t)63;
     o->pack_floats = n_pad + row;
     int r = oalloc(o, &o->pack, o->pack_floats);
-    if (r == NST_OK && hipMemset(o->pack, 0, o->pack_floats * sizeof(float)) != hipSuccess) r = NST_E_HIP;
+    if (r == NST_OK && nst_internal_zero_now(o->pack, o->pack_floats * sizeof(float))) r = NST_E_HIP;
     o->g = o->own_g = o->pack;
     o->losses = o->own_losses = o->pack ? o->pack + n_pad : nullptr;
     if (r == NST_OK) r = oalloc(o, &o->scal, 4);
@@ -493,7 +496,7 @@ int nst_opt_create(nst_ctx* ctx, int kind, float lr_start, int lbfgs_max_eval, n
     if (r == NST_OK && kind == NST_OPT_ADAM) {
         r = oalloc(o, &o->m, o->n);
         if (r == NST_OK) r = oalloc(o, &o->v, o->n);
-        if (r == NST_OK && (hipMemset(o->m, 0, o->n * 4) != hipSuccess || hipMemset(o->v, 0, o->n * 4) != hipSuccess)) r = NST_E_HIP;
+        if (r == NST_OK && (nst_internal_zero_now(o->m, o->n * 4) || nst_internal_zero_now(o->v, o->n * 4))) r = NST_E_HIP;
     }
     if (r == NST_OK && kind == NST_OPT_LBFGS) {
         r = oalloc(o, &o->d, o->n);

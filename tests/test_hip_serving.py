@@ -213,6 +213,57 @@ def test_two_jobs_on_one_gpu_do_not_disturb_each_other(vgg_weights):
     assert torch.equal(alone["x"], shared["x"])
 
 
+def test_job_setup_does_not_ride_on_the_null_stream(vgg_weights):
+    """A job set up and run while ANOTHER thread keeps the null stream busy (a second tenant's torch work on the default
+    stream) must give the results of the same job on an idle GPU.  hipMemset on device memory is enqueued on the null
+    stream and returns before it has run: the set-up zero fills (absmax records of the style image's activations, Adam
+    moments, the packed rows) used to land behind that other work - after this job's first kernels on its own
+    non-blocking stream - and wiped what those had written: a zero absmax record -> an overflowing operand scale -> NaN
+    style targets.  The flaky form of this was test_two_jobs_on_one_gpu_do_not_disturb_each_other (5 of 8 runs red on
+    the build before the fix; the other context's set_targets on the default stream was the trigger)."""
+    from artstyletransfer_amd.engine import PixelOptimizer, StyleEngine
+    c, s = levels(128, 192, 2, 5), levels(128, 192, 2, 6)
+    st = torch.cuda.Stream()
+
+    def job(kind):
+        with torch.cuda.stream(st):
+            e = StyleEngine(vgg_weights, 0)
+            setup(e, c, s)
+            x = dev(cpu_ref.prepare_img(c[0]))
+            opt = PixelOptimizer(e, kind, 1.0, 26) if kind == "lbfgs" else PixelOptimizer(e, kind)
+            rows = [opt.step(x, CW, SW, TVW)[1].copy() for _ in range(6)]
+            st.synchronize()
+            out = np.concatenate(rows), x.cpu()
+            opt.close()
+            e.close()
+        return out
+
+    stop = threading.Event()
+
+    def neighbour():                             # keeps a few ms of kernels queued on the null stream at all times
+        a = torch.randn(2048, 2048, device="cuda:0")
+        while not stop.is_set():
+            b = a
+            for _ in range(16):
+                b = (b @ b) * 1e-3
+            torch.cuda.default_stream().synchronize()
+
+    for kind in ("adam", "lbfgs"):
+        torch.cuda.synchronize()
+        rows0, x0 = job(kind)
+        stop.clear()
+        t = threading.Thread(target=neighbour)
+        t.start()
+        try:
+            for _ in range(3):
+                rows1, x1 = job(kind)
+                assert np.array_equal(rows0, rows1), kind
+                assert torch.equal(x0, x1), kind
+        finally:
+            stop.set()
+            t.join()
+
+
 def test_real_weights_path_end_to_end(tmp_path, monkeypatch, vgg_weights):
     """neural_nets.load_weights (replaces the pretrained fetch of neural_nets.py:19) -> Vgg19.forward on the device: a
     torchvision-style state dict with NON-ZERO biases written to a file, found through NST_VGG19_WEIGHTS, must give the
