@@ -143,10 +143,18 @@ class Executor:
             await asyncio.sleep(1)
 
     async def wait_all(self):
-        """Extension: wait until every task added so far has finished."""
+        """Extension: wait until every task added so far has finished.  A job that ended in an exception never calls
+        job_done (as in the reference, task_executor.py:28-43, where such a task stays listed for ever): it is taken off
+        the list here and its exception re-raised, instead of being waited for again and again."""
         while True:
             async with self.__tasks_lock:
-                jobs = [t.job for t in self.__tasks.values()]
+                jobs = {t.job: tid for tid, t in self.__tasks.items()}
             if not jobs:
                 return
-            await asyncio.wait(jobs)
+            done, _ = await asyncio.wait(jobs.keys(), return_when=asyncio.FIRST_EXCEPTION)
+            for job in done:
+                if job.cancelled() or job.exception() is not None:
+                    async with self.__tasks_lock:
+                        self.__tasks.pop(jobs[job], None)
+                    if not job.cancelled():
+                        raise job.exception()

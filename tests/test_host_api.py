@@ -373,6 +373,31 @@ def test_job_failure_releases_its_gpu(monkeypatch):
     asyncio.run(main())
 
 
+def test_wait_all_reraises_a_failed_job_and_lets_the_others_finish(monkeypatch):
+    """A failed job never calls job_done (as in the reference): wait_all used to wait for it again and again."""
+    from artstyletransfer_amd import config, task_executor as te
+
+    async def sometimes(pair, *args, device=None):
+        if pair.content[0] == "bad":
+            raise RuntimeError("boom")
+        for k in range(3):
+            await asyncio.sleep(0.01)
+            yield (k + 1) / 3 * 100.0, np.zeros((2, 2, 3), np.float32)
+
+    monkeypatch.setattr(te, "neural_style_transfer", sometimes)
+
+    async def main():
+        ex = te.Executor(config.Config(), gpu_slots=te.GpuSlots(per_gpu=2, n_gpus=1))
+        await ex.add_task("good", te.ContentStylePair(("ok", None), ("s", None)))
+        await ex.add_task("bad", te.ContentStylePair(("bad", None), ("s", None)))
+        with pytest.raises(RuntimeError, match="boom"):
+            await asyncio.wait_for(ex.wait_all(), timeout=5)
+        await asyncio.wait_for(ex.wait_all(), timeout=5)          # the failed task is off the list; the good one completes
+        assert (await ex.get_progress("good"))[0] == pytest.approx(100.0)
+
+    asyncio.run(main())
+
+
 def test_process_rejects_unknown_optimizer_and_model():
     import neural_style_transfer as nst
 

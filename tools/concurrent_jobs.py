@@ -1,6 +1,7 @@
 """GPU: J style-transfer jobs sharing ONE MI355X through the public scheduler (Executor + GpuSlots, the reference's
 `simultaneous_tasks_count` jobs per GPU): aggregate closure rate in the window in which all J jobs are stepping.
-   python tools/concurrent_jobs.py [iters=400] [J ...=1 2 3]"""
+   NST_SYNTHETIC_WEIGHTS=1 python tools/concurrent_jobs.py [iters=400] [J ...=1 2 3]      (or NST_VGG19_WEIGHTS=<checkpoint>)
+Every yielded image is checked for finiteness; a failed job is re-raised by Executor.wait_all."""
 import asyncio, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
